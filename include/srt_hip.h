@@ -1,0 +1,270 @@
+/*
+ * srt_hip.h -- C ABI of the MI355X-native path-tracing hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  It sits where the reference keeps its (disabled) device seam
+ *
+ *     glDevice::init(w, h, std::vector<hittableIndexed>&)       gl.h:28, gl.h:194-267
+ *     glDevice::rtFrame(void* frame, w, h, objects)             gl.h:29, gl.h:269-320
+ *     glDevice::terminate()                                     gl.h:30
+ *     hittableVector::build(list) / hittable::populateVector    hittablevector.h:27-31, hittable.h:32
+ *
+ * and replaces the body of the integrator loop main.cpp:200-227 (pixel/sample
+ * loop -> camera::getRay -> rayColor -> writeColorTarget).
+ *
+ * Conventions (the reference's: bool returns + text on stderr, caller-owned
+ * pixel buffers, main.cpp:182,239): every entry point returns int, 0 = ok,
+ * non-zero = error with text available from srtLastError().  No exceptions
+ * cross this boundary.  One context per GPU; calls on one context are not
+ * thread-safe; different contexts may be driven from different host threads.
+ */
+#ifndef SRT_HIP_H
+#define SRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ enums */
+enum { SRT_PRIM_TRIANGLE = 0, SRT_PRIM_SPHERE = 1 };
+/* material.h: pbrMetallicRoughness :23, metal :87, dielectric :104, diffuseLight :139 */
+enum { SRT_MAT_PBR = 0, SRT_MAT_METAL = 1, SRT_MAT_DIELECTRIC = 2, SRT_MAT_LIGHT = 3 };
+/* texture.h: solidColor :18, checker :34, imagePNG/image3bpp :109/:54 */
+enum { SRT_TEX_SOLID = 0, SRT_TEX_CHECKER = 1, SRT_TEX_IMAGE = 2 };
+enum { SRT_WORLD_PRIM = 0, SRT_WORLD_BVH = 1 };
+/* traversal semantics: FAITHFUL = bvh.h:97-105 order with triangle::hit's
+ * missing tMax test (model.h:128); CLOSEST adds the t < closest test. */
+enum { SRT_TRAVERSE_FAITHFUL = 0, SRT_TRAVERSE_CLOSEST = 1 };
+
+#define SRT_TILE_W 8
+#define SRT_TILE_H 8
+#define SRT_TILE_PIXELS 64
+#define SRT_MAX_BOUNCE 16
+#define SRT_NO_HIT (-1)
+
+/* ------------------------------------------------- scene description (in) */
+
+/* One triangle with its vertex data already gathered through the mesh's u16
+ * indices (model.h:108-111).  64 bytes. */
+typedef struct SrtTriangleIn {
+  float p[3][3];   /* positions  parentMesh->positions[vertices[i]]  */
+  float uv[3][2];  /* texcoords  parentMesh->texcoords[vertices[i]]  */
+  int32_t material;
+} SrtTriangleIn;
+
+/* sphere.h:11-15 ctor arguments. */
+typedef struct SrtSphereIn {
+  float center0[3];
+  float center1[3];
+  float time0, time1;
+  float radius;
+  int32_t material;
+} SrtSphereIn;
+
+/* One entry of a hittableList::objects vector (hittablelist.h:30), in list order. */
+typedef struct SrtPrimRef {
+  int32_t type;  /* SRT_PRIM_* */
+  int32_t index; /* into triangles[] or spheres[] */
+} SrtPrimRef;
+
+/* One entry of the world list handed to rayColor (main.cpp:146,187):
+ * a bare primitive, or a bvhNode built over prims[first, first+count)
+ * with the (time0,time1) given to its ctor (bvh.h:15-16). */
+typedef struct SrtWorldItem {
+  int32_t kind; /* SRT_WORLD_* */
+  int32_t first;
+  int32_t count;
+  float time0, time1;
+} SrtWorldItem;
+
+/* material.h.  Field use per type:
+ *   PBR        albedoTex/normalTex/metallicTex/roughnessTex (-1 = null ptr),
+ *              albedo[4] = albedo factor, metalness, roughness
+ *   METAL      albedo[0..2] = albedo, fuzz (already clamped to <=1 by the ctor, :89)
+ *   DIELECTRIC ir
+ *   LIGHT      albedoTex = emit texture                                        */
+typedef struct SrtMaterialIn {
+  int32_t type;
+  int32_t albedoTex, normalTex, metallicTex, roughnessTex;
+  float albedo[4];
+  float metalness, roughness;
+  float fuzz, ir;
+  int32_t pad[3];
+} SrtMaterialIn;
+
+/* texture.h.  IMAGE: width*height*bpp bytes at texels + texelOffset, row
+ * stride bpp*width (texture.h:122); width==0 means "failed to load" and
+ * samples as (1,0,1) (texture.h:130-131).  CHECKER: even/odd are texture
+ * ids of SOLID or IMAGE textures (texture.h:37-40). */
+typedef struct SrtTextureIn {
+  int32_t kind;
+  int32_t width, height, bpp;
+  int64_t texelOffset;
+  int32_t even, odd;
+  float color[3];
+  int32_t pad;
+} SrtTextureIn;
+
+typedef struct SrtSceneDesc {
+  int32_t numTriangles;
+  const SrtTriangleIn* triangles;
+  int32_t numSpheres;
+  const SrtSphereIn* spheres;
+  int32_t numPrims;
+  const SrtPrimRef* prims; /* list order: decides BVH sort ties */
+  int32_t numWorld;
+  const SrtWorldItem* world;
+  int32_t numMaterials;
+  const SrtMaterialIn* materials;
+  int32_t numTextures;
+  const SrtTextureIn* textures;
+  int64_t numTexelBytes;
+  const uint8_t* texels;
+} SrtSceneDesc;
+
+/* camera.h:10-38 ctor arguments, and the members the ctor derives. */
+typedef struct SrtCameraParams {
+  float eye[3], lookAt[3], up[3];
+  float vfovDegrees, aspect, aperture, focusDist, time0, time1;
+} SrtCameraParams;
+
+typedef struct SrtCamera {
+  float origin[3], lleft[3], horizontal[3], vertical[3];
+  float w[3], hor[3], vert[3];
+  float lensRadius, time0, time1;
+} SrtCamera;
+
+/* ------------------------------------------------------ flattened BVH (out) */
+/* 32 bytes: one node visit = two 16-byte loads.  child >= 0: node index in
+ * the same array; child < 0: primitive, ~child = index into prims[]. */
+typedef struct SrtBvhNode {
+  float bmin[3];
+  int32_t left;
+  float bmax[3];
+  int32_t right;
+} SrtBvhNode;
+
+/* ----------------------------------------------------------- fixed ray set */
+typedef struct SrtRay {
+  float o[3];
+  float d[3];
+  float time;
+  float tMin, tMax;
+} SrtRay;
+
+/* hitRecord (hittable.h:9-22) plus what the reference never records: the
+ * primitive id (index into prims[]) and traversal counters. */
+typedef struct SrtHit {
+  int32_t prim; /* SRT_NO_HIT on miss */
+  float t;
+  float p[3];
+  float normal[3], tangent[3], bitangent[3];
+  float uv[2];
+  int32_t frontFace;
+  int32_t material;
+  int32_t nodeVisits, boxPasses, triTests, sphereTests;
+} SrtHit;
+
+/* ----------------------------------------------------------------- render */
+typedef struct SrtRenderParams {
+  int32_t imageWidth, imageHeight;
+  int32_t spp;       /* numSamples, main.cpp:178 */
+  int32_t maxBounce; /* main.cpp:180 */
+  uint64_t seed;     /* counter RNG key; see DESIGN.md "RNG" */
+  float background[3]; /* main.cpp:170 */
+  float tMin;          /* 0.001f, main.cpp:39 */
+  int32_t traversal;   /* SRT_TRAVERSE_* */
+  /* multi-GPU tile split: this call renders tiles tileFirst, tileFirst+tileStride, ... */
+  int32_t tileFirst, tileStride;
+  /* samples of one pixel are summed in index order inside one chunk (the
+   * reference's order, main.cpp:204-218); chunks > 1 splits spp into that many
+   * partial sums combined in chunk order (for small images). */
+  int32_t sppChunks;
+  int32_t countStats; /* 1: run the counting variant and fill srtGetStats() */
+} SrtRenderParams;
+
+/* counters behind the algorithmic-bytes figure */
+typedef struct SrtStats {
+  uint64_t samples, rays;
+  uint64_t nodeVisits, boxPasses, triTests, sphereTests;
+  uint64_t shadedTriHits, texelFetches;
+} SrtStats;
+
+typedef struct SrtContext SrtContext;
+
+/* ------------------------------------------------------------ entry points */
+
+/* replaces glDevice::init's context part (gl.h:194-215). */
+int srtCreate(int deviceOrdinal, SrtContext** out);
+/* replaces glDevice::terminate (gl.h:322-324). */
+int srtDestroy(SrtContext* ctx);
+const char* srtLastError(const SrtContext* ctx);
+
+/* Host helper: camera ctor arithmetic, camera.h:10-38 (double tan, etc). */
+int srtMakeCamera(const SrtCameraParams* in, SrtCamera* out);
+
+/* The process-global default-seeded mt19937 the reference draws everything
+ * from (globals.h:30-35).  The BVH builder consumes it exactly as
+ * bvh.h:60 does; scene code may use it as randomFloat(). */
+float srtHostRandomFloat(void);
+void srtHostRandomReset(void);
+
+/* replaces hittableVector::build + the SSBO upload (hittablevector.h:27-31,
+ * gl.h:240-262): builds every SRT_WORLD_BVH with bvh.h:55-95 semantics,
+ * precomputes per-triangle constants, copies everything to HBM. */
+int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* scene);
+int srtSetCamera(SrtContext* ctx, const SrtCamera* cam);
+
+/* Host-only (no GPU needed): the bvhNode build of world item `item`, exactly as
+ * srtUploadScene performs it.  out may be NULL to query the node count. */
+int srtBuildBvh(const SrtSceneDesc* scene, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count,
+                int32_t* stackDepth);
+
+/* Flattened tree of world item `item` (host copy), for topology parity tests.
+ * Call with nodes == NULL to get the count. */
+int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count);
+int srtGetBvhDepth(SrtContext* ctx, int32_t* depth);
+
+/* Tiles: the image is cut into 8x8-pixel tiles, row-major tile ids; one
+ * wavefront renders one tile (lane = pixel).  srtNumLocalTiles gives the
+ * (rank-padded) tile count of one rank: ceil(numTiles / tileStride). */
+int32_t srtNumTiles(int32_t imageWidth, int32_t imageHeight);
+int32_t srtNumLocalTiles(int32_t imageWidth, int32_t imageHeight, int32_t tileStride);
+
+/* The hot path.  Asynchronous on `stream` (a hipStream_t, NULL = default).
+ * dAccumTiles: DEVICE pointer, float4[numLocalTiles * 64], tile-major,
+ * rgb = sum over samples of rayColor, a = sample count. */
+int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* stream);
+
+/* color.h:25-41 (writeColorTarget) over a gathered, rank-major tile buffer
+ * float4[tileStride][numLocalTiles*64]: un-permutes tiles into image order.
+ * dRgba: DEVICE uint8[W*H*4] or NULL; dAccumImage: DEVICE float4[W*H] or NULL. */
+int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGatheredTiles,
+                    void* dRgba, void* dAccumImage, void* stream);
+
+/* Blocking convenience with caller-owned HOST buffers: the main.cpp:182,224
+ * `target` contract.  hAccum (float[W*H*4]) and hRgba (uint8[W*H*4]) may be NULL. */
+int srtRenderImage(SrtContext* ctx, const SrtRenderParams* p, float* hAccum, uint8_t* hRgba);
+
+/* Fixed-ray-set parity entry: world.hit(r, tMin, tMax, rec) for n rays. HOST pointers. */
+int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, int32_t traversal);
+
+/* Test hook: material::scatter + emitted (material.h:15-21) through the kernel's own
+ * shading function for n (ray, hit record) pairs; entry i draws from the counter RNG
+ * keyed (seed, pixel=i, sample=0).  out13 per entry: attenuation[3], scattered dir[3],
+ * scattered origin[3], scatter's bool, emitted[3].  HOST pointers. */
+int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
+
+/* Duration of the most recent srtRenderTiles kernel, from HIP events recorded
+ * on its stream (synchronises on the stop event). */
+int srtLastKernelMs(SrtContext* ctx, float* ms);
+int srtGetStats(SrtContext* ctx, SrtStats* out);
+/* device properties the bench prints next to its numbers */
+int srtDeviceInfo(SrtContext* ctx, char* name, int32_t nameCap, int32_t* numCUs, int32_t* clockMHz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_HIP_H */

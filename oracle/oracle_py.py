@@ -1,0 +1,136 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE (see oracle.cpp header).
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+abi = importlib.import_module("sexy-raytracer_amd.abi")
+
+RNG_MT, RNG_COUNTER = 0, 1
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "nodeVisits", "boxPasses", "triCalls", "sphereCalls",
+                                          "dupTri", "dupSphere", "shadedTriHits", "texelFetches", "rngDraws")]
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d["triTests"] = d["triCalls"] - d["dupTri"]
+        d["sphereTests"] = d["sphereCalls"] - d["dupSphere"]
+        return d
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(abi.SrtSceneDesc)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_build_draws.restype = C.c_uint64
+        L.orc_build_draws.argtypes = [C.c_void_p]
+        L.orc_make_camera.argtypes = [C.POINTER(abi.SrtCameraParams), C.POINTER(abi.SrtCamera)]
+        L.orc_rng_kat.argtypes = [C.c_int, C.c_void_p]
+        L.orc_rng_kat_libstdcxx.argtypes = [C.c_int, C.c_void_p]
+        L.orc_rng_counter.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_random_vec3_kat.argtypes = [C.c_void_p]
+        L.orc_bvh_flatten.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        L.orc_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(abi.SrtCamera), C.POINTER(abi.SrtRenderParams), C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+        L.orc_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def make_camera(params):
+    cam = abi.SrtCamera()
+    lib().orc_make_camera(C.byref(params), C.byref(cam))
+    return cam
+
+
+def rng_kat(n, libstdcxx=False):
+    out = np.zeros(n, np.float32)
+    (lib().orc_rng_kat_libstdcxx if libstdcxx else lib().orc_rng_kat)(n, out.ctypes.data)
+    return out
+
+
+def rng_counter(seed, pixel, sample, n):
+    out = np.zeros(n, np.float32)
+    lib().orc_rng_counter(seed, pixel, sample, n, out.ctypes.data)
+    return out
+
+
+class OracleScene:
+    def __init__(self, scene_builder):
+        self.sb = scene_builder
+        self.desc = scene_builder.desc()
+        self.h = lib().orc_scene_create(C.byref(self.desc))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def build_draws(self):
+        return int(lib().orc_build_draws(self.h))
+
+    def bvh(self, item=0):
+        n, d = C.c_int(0), C.c_int(0)
+        rc = lib().orc_bvh_flatten(self.h, item, None, 0, C.byref(n), C.byref(d))
+        assert rc == 0
+        nodes = np.zeros(n.value, abi.NODE_DTYPE)
+        rc = lib().orc_bvh_flatten(self.h, item, nodes.ctypes.data, n.value, C.byref(n), C.byref(d))
+        assert rc == 0
+        return nodes, d.value
+
+    def trace(self, rays, traversal=abi.SRT_TRAVERSE_FAITHFUL):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        hits = np.zeros(len(rays), abi.HIT_DTYPE)
+        lib().orc_trace(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, traversal)
+        return hits
+
+    def scatter(self, ray, hit, seed, pixel, sample):
+        ray = np.ascontiguousarray(ray, abi.RAY_DTYPE)
+        hit = np.ascontiguousarray(hit, abi.HIT_DTYPE)
+        out = np.zeros(13, np.float32)
+        lib().orc_scatter(self.h, ray.ctypes.data, hit.ctypes.data, seed, pixel, sample, out.ctypes.data)
+        return out
+
+    def render(self, cam, params, rng_mode=RNG_COUNTER, threads=8, rows=None, want_rgba=True, want_stats=True):
+        W, H = params.imageWidth, params.imageHeight
+        accum = np.zeros((H, W, 4), np.float32)
+        rgba = np.zeros((H, W, 4), np.uint8) if want_rgba else None
+        st = OrcStats()
+        r0, r1 = rows if rows is not None else (0, H)
+        lib().orc_render(self.h, C.byref(cam), C.byref(params), rng_mode, threads, r0, r1, accum.ctypes.data,
+                         rgba.ctypes.data if rgba is not None else None, C.byref(st) if want_stats else None)
+        return accum, rgba, st.as_dict()
+
+
+def resolve(accum, spp):
+    H, W = accum.shape[:2]
+    out = np.zeros((H, W, 4), np.uint8)
+    a = np.ascontiguousarray(accum, np.float32)
+    lib().orc_resolve(a.ctypes.data, W, H, spp, out.ctypes.data)
+    return out

@@ -1,0 +1,768 @@
+// srt_api.cpp -- host side of the C ABI (include/srt_hip.h): context, scene flattening,
+// the reference-order BVH build, uploads, launches and timing.
+//
+// Host arithmetic that feeds the kernels (BVH boxes, per-triangle normals and tangent
+// frames, the camera frame) keeps the reference's operation order; this file is built
+// with -ffp-contract=off and without -march so it rounds like the reference's x86-64 build.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "srt_device.h"
+
+extern "C" {
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU);
+int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
+int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
+int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
+                       hipStream_t stream);
+}
+
+namespace {
+
+// ------------------------------------------------------------------ host vector math
+struct H3 {
+  float x, y, z;
+};
+inline H3 h3(const float* p) { return H3{p[0], p[1], p[2]}; }
+inline H3 operator+(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 operator-(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 operator*(float s, H3 a) { return H3{s * a.x, s * a.y, s * a.z}; }
+inline H3 operator/(H3 a, float s) { return H3{a.x / s, a.y / s, a.z / s}; }
+inline H3 crossH(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float lenSqH(H3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }  // vec3.h:29-31
+inline H3 unitH(H3 v) {                                                    // vec3.h:54-60
+  float len = sqrtf(lenSqH(v));
+  if (len != 0) return H3{v.x / len, v.y / len, v.z / len};
+  return v;
+}
+
+struct Box {
+  float mn[3], mx[3];
+};
+inline Box surrounding(const Box& a, const Box& b) {  // aabb.h:33-43
+  Box r;
+  for (int k = 0; k < 3; ++k) {
+    r.mn[k] = fminf(a.mn[k], b.mn[k]);
+    r.mx[k] = fmaxf(a.mx[k], b.mx[k]);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ the global generator
+// globals.h:30-35: function-local static default-seeded mt19937 + uniform_real_distribution<float>(0,1)
+std::mt19937& hostGenerator() {
+  static std::mt19937 generator;
+  return generator;
+}
+float hostRandomFloat() {
+  static std::uniform_real_distribution<float> distribution(0.0f, 1.0f);
+  return distribution(hostGenerator());
+}
+int hostRandomInt(int lo, int hi) {  // globals.h:37-43
+  float a = (float)lo, b = (float)(hi + 1);
+  return static_cast<int>(a + (b - a) * hostRandomFloat());
+}
+
+// ------------------------------------------------------------------ primitives on the host
+Box sphereBoxAt(const SrtSphereIn& s, float time) {  // sphere.h:47-52, 86-89
+  H3 c0 = h3(s.center0), c1 = h3(s.center1);
+  H3 c = c0;
+  if (c0.x != c1.x || c0.y != c1.y || c0.z != c1.z) c = c0 + ((time - s.time0) / (s.time1 - s.time0)) * (c1 - c0);
+  Box b;
+  b.mn[0] = c.x - s.radius; b.mn[1] = c.y - s.radius; b.mn[2] = c.z - s.radius;
+  b.mx[0] = c.x + s.radius; b.mx[1] = c.y + s.radius; b.mx[2] = c.z + s.radius;
+  return b;
+}
+Box sphereBox(const SrtSphereIn& s, float t0, float t1) {  // sphere.h:85-94
+  return surrounding(sphereBoxAt(s, t0), sphereBoxAt(s, t1));
+}
+Box triangleBox(const SrtTriangleIn& t) {  // model.h:183-212
+  const float inf = std::numeric_limits<float>::infinity();
+  Box b;
+  for (int a = 0; a < 3; ++a) {
+    b.mn[a] = inf;
+    b.mx[a] = -inf;
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int a = 0; a < 3; ++a) {
+      b.mn[a] = std::min(b.mn[a], t.p[k][a]);
+      b.mx[a] = std::max(b.mx[a], t.p[k][a]);
+    }
+  for (int a = 0; a < 3; ++a)
+    if (b.mn[a] == b.mx[a]) {
+      b.mn[a] -= 0.0001f;
+      b.mx[a] += 0.0001f;
+    }
+  return surrounding(b, b);
+}
+
+// ------------------------------------------------------------------ bvh.h:55-95
+struct BuildNode {
+  Box box;
+  int32_t left, right;  // >= 0 node, < 0 ~primListIndex
+};
+
+struct Builder {
+  const SrtSceneDesc* d;
+  float time0, time1;
+  std::vector<float> sortKey;    // boundingBox(0,0).minimum per prim (boxCompare, bvh.h:34-41), 3 per prim
+  std::vector<int32_t> objects;  // prim list indices; the reference's `objects` vector
+  std::vector<BuildNode> nodes;
+  int maxPending = 0;
+
+  Box primBox(int32_t prim, float t0, float t1) const {
+    const SrtPrimRef& pr = d->prims[prim];
+    return pr.type == SRT_PRIM_SPHERE ? sphereBox(d->spheres[pr.index], t0, t1) : triangleBox(d->triangles[pr.index]);
+  }
+  Box childBox(int32_t ref) const { return ref >= 0 ? nodes[ref].box : primBox(~ref, time0, time1); }
+
+  // The reference copies the object vector at each node (bvh.h:57) and sorts [start,end)
+  // of the copy; sibling subtrees only touch disjoint sub-ranges, so one shared vector
+  // sorted in place gives the same tree.  Nodes are emitted in pre-order (the order
+  // populateVector walks them, bvh.h:112-148).
+  int32_t build(size_t start, size_t end, int pending) {
+    int axis = hostRandomInt(0, 2);  // bvh.h:60: one draw per node, pre-order
+    auto comparator = [this, axis](int32_t a, int32_t b) { return sortKey[3 * a + axis] < sortKey[3 * b + axis]; };
+    int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    size_t span = end - start;
+    int32_t left, right;
+    if (span == 1) {
+      left = right = ~objects[start];
+    } else if (span == 2) {
+      if (comparator(objects[start], objects[start + 1])) {
+        left = ~objects[start];
+        right = ~objects[start + 1];
+      } else {
+        left = ~objects[start + 1];
+        right = ~objects[start];
+      }
+      maxPending = std::max(maxPending, pending + 1);
+    } else {
+      std::sort(objects.begin() + start, objects.begin() + end, comparator);
+      size_t mid = start + span / 2;
+      maxPending = std::max(maxPending, pending + 1);
+      left = build(start, mid, pending + 1);
+      right = build(mid, end, pending);
+    }
+    BuildNode& n = nodes[me];
+    n.left = left;
+    n.right = right;
+    n.box = surrounding(childBox(left), childBox(right));  // bvh.h:88-94
+    return me;
+  }
+};
+
+// make_shared<bvhNode>(objects, time0, time1) over one world item (main.cpp:146, bvh.h:15-16)
+void buildItem(const SrtSceneDesc* d, const SrtWorldItem& it, Builder& b) {
+  b.d = d;
+  b.time0 = it.time0;
+  b.time1 = it.time1;
+  b.sortKey.resize((size_t)d->numPrims * 3);
+  b.objects.resize(it.count);
+  for (int i = 0; i < it.count; ++i) {
+    int prim = it.first + i;
+    b.objects[i] = prim;
+    Box bx = b.primBox(prim, 0, 0);  // boxCompare uses boundingBox(0, 0, ...) (bvh.h:37)
+    for (int k = 0; k < 3; ++k) b.sortKey[3 * prim + k] = bx.mn[k];
+  }
+  b.nodes.reserve((size_t)it.count * 2);
+  b.build(0, it.count, 0);
+}
+
+// ------------------------------------------------------------------ context
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct SrtContext {
+  int device = 0;
+  std::string error;
+  hipDeviceProp_t prop;
+  // device scene
+  std::vector<DeviceBuffer> sceneBuffers;
+  DevScene scene{};
+  DevCamera cam{};
+  bool haveScene = false, haveCamera = false;
+  // host copies for srtGetBvh
+  std::vector<std::vector<SrtBvhNode>> itemNodes;
+  int bvhDepth = 0;
+  // work areas
+  int32_t* dQueue = nullptr;
+  unsigned long long* dStats = nullptr;
+  DeviceBuffer chunkScratch;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  bool timed = false;
+  SrtStats lastStats{};
+};
+
+namespace {
+
+int fail(SrtContext* ctx, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->error = buf;
+  fprintf(stderr, "srt_hip: %s\n", buf);  // the reference reports on std::cerr (texture.h:64-67, bvh.h:37-38)
+  return 1;
+}
+
+#define HIP_OK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) return fail(ctx, "%s -> %s", #call, hipGetErrorString(e_));       \
+  } while (0)
+
+template <typename T>
+int uploadVec(SrtContext* ctx, const std::vector<T>& v, const T** out, size_t padBytes = 0) {
+  DeviceBuffer b;
+  b.bytes = std::max<size_t>(v.size() * sizeof(T) + padBytes, 16);
+  HIP_OK(ctx, hipMalloc(&b.p, b.bytes));
+  HIP_OK(ctx, hipMemset(b.p, 0, b.bytes));
+  if (!v.empty()) HIP_OK(ctx, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ctx->sceneBuffers.push_back(b);
+  *out = static_cast<const T*>(b.p);
+  return 0;
+}
+
+void freeScene(SrtContext* ctx) {
+  for (auto& b : ctx->sceneBuffers) (void)hipFree(b.p);
+  ctx->sceneBuffers.clear();
+  ctx->haveScene = false;
+}
+
+size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
+  return (size_t)(ctx->scene.stackDepth + 3 * maxBounce) * 256 * sizeof(int32_t);
+}
+
+}  // namespace
+
+
+namespace {
+// every index the kernels (and the host builder) will follow
+int validateScene(SrtContext* ctx, const SrtSceneDesc* d) {
+  for (int i = 0; i < d->numTextures; ++i) {
+    const SrtTextureIn& t = d->textures[i];
+    if (t.kind == SRT_TEX_CHECKER) {
+      for (int c : {t.even, t.odd})
+        if (c < 0 || c >= d->numTextures || d->textures[c].kind == SRT_TEX_CHECKER)
+          return fail(ctx, "texture %d: checker children must be solid or image textures", i);
+    } else if (t.kind == SRT_TEX_IMAGE) {
+      if (t.width < 0 || t.height < 0 || (t.width > 0 && (t.bpp < 1 || t.bpp > 4)))
+        return fail(ctx, "texture %d: bad image dimensions", i);
+      if (t.width > 0 && (t.texelOffset < 0 || t.texelOffset + (int64_t)t.width * t.height * t.bpp > d->numTexelBytes))
+        return fail(ctx, "texture %d: texels out of range", i);
+    } else if (t.kind != SRT_TEX_SOLID)
+      return fail(ctx, "texture %d: unknown kind %d", i, t.kind);
+  }
+  auto texOk = [&](int id) { return id >= -1 && id < d->numTextures; };
+  for (int i = 0; i < d->numMaterials; ++i) {
+    const SrtMaterialIn& m = d->materials[i];
+    if (m.type < SRT_MAT_PBR || m.type > SRT_MAT_LIGHT) return fail(ctx, "material %d: unknown type %d", i, m.type);
+    if (!texOk(m.albedoTex) || !texOk(m.normalTex) || !texOk(m.metallicTex) || !texOk(m.roughnessTex))
+      return fail(ctx, "material %d: texture id out of range", i);
+    if (m.type == SRT_MAT_LIGHT && m.albedoTex < 0) return fail(ctx, "material %d: light without emit texture", i);
+  }
+  for (int i = 0; i < d->numTriangles; ++i)
+    if (d->triangles[i].material < 0 || d->triangles[i].material >= d->numMaterials)
+      return fail(ctx, "triangle %d: material out of range", i);
+  for (int i = 0; i < d->numSpheres; ++i)
+    if (d->spheres[i].material < 0 || d->spheres[i].material >= d->numMaterials)
+      return fail(ctx, "sphere %d: material out of range", i);
+  for (int i = 0; i < d->numPrims; ++i) {
+    const SrtPrimRef& p = d->prims[i];
+    int lim = p.type == SRT_PRIM_SPHERE ? d->numSpheres : p.type == SRT_PRIM_TRIANGLE ? d->numTriangles : -1;
+    if (p.index < 0 || p.index >= lim) return fail(ctx, "prim %d: bad type/index", i);
+  }
+  for (int w = 0; w < d->numWorld; ++w) {
+    const SrtWorldItem& it = d->world[w];
+    if (it.first < 0 || it.count < 1 || it.first + it.count > d->numPrims || (it.kind != SRT_WORLD_PRIM && it.kind != SRT_WORLD_BVH))
+      return fail(ctx, "world item %d: bad range", w);
+  }
+
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int srtCreate(int deviceOrdinal, SrtContext** out) {
+  if (!out) return 1;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, "no HIP device available (%s)", hipGetErrorString(e));
+  if (deviceOrdinal < 0 || deviceOrdinal >= n) return fail(nullptr, "device ordinal %d out of range [0,%d)", deviceOrdinal, n);
+  SrtContext* ctx = new SrtContext();
+  ctx->device = deviceOrdinal;
+  HIP_OK(ctx, hipSetDevice(deviceOrdinal));
+  HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, 64));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 8 * sizeof(unsigned long long)));
+  HIP_OK(ctx, hipEventCreate(&ctx->evStart));
+  HIP_OK(ctx, hipEventCreate(&ctx->evStop));
+  *out = ctx;
+  return 0;
+}
+
+int srtDestroy(SrtContext* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  freeScene(ctx);
+  if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
+  if (ctx->dQueue) (void)hipFree(ctx->dQueue);
+  if (ctx->dStats) (void)hipFree(ctx->dStats);
+  if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+  if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+  delete ctx;
+  return 0;
+}
+
+const char* srtLastError(const SrtContext* ctx) { return ctx ? ctx->error.c_str() : "no context"; }
+
+float srtHostRandomFloat(void) { return hostRandomFloat(); }
+void srtHostRandomReset(void) { hostGenerator().seed(std::mt19937::default_seed); }
+
+// camera.h:10-38
+int srtMakeCamera(const SrtCameraParams* in, SrtCamera* out) {
+  if (!in || !out) return 1;
+  const float pi = 3.1415926535897932385f;
+  H3 eye = h3(in->eye), lookAt = h3(in->lookAt), up = h3(in->up);
+  float theta = in->vfovDegrees * pi / 180.0f;  // deg2rad, globals.h:26-28
+  double h = tan((double)(theta / 2.0f));       // camera.h:20: tan(float) is the double overload
+  double vpHeight = 2.0f * h;
+  double vpWidth = in->aspect * vpHeight;
+  H3 w = unitH(eye - lookAt);
+  H3 hor = unitH(crossH(up, w));
+  H3 vert = unitH(crossH(w, hor));
+  H3 horizontal = (float)(in->focusDist * vpWidth) * hor;  // Eigen casts the double scalar to float
+  H3 vertical = (float)(in->focusDist * vpHeight) * vert;
+  H3 lleft = eye - horizontal / 2.0f - vertical / 2.0f - in->focusDist * w;
+  const H3* src[] = {&eye, &lleft, &horizontal, &vertical, &w, &hor, &vert};
+  float* dst[] = {out->origin, out->lleft, out->horizontal, out->vertical, out->w, out->hor, out->vert};
+  for (int i = 0; i < 7; ++i) {
+    dst[i][0] = src[i]->x;
+    dst[i][1] = src[i]->y;
+    dst[i][2] = src[i]->z;
+  }
+  out->lensRadius = in->aperture / 2.0f;
+  out->time0 = in->time0;
+  out->time1 = in->time1;
+  return 0;
+}
+
+int srtSetCamera(SrtContext* ctx, const SrtCamera* c) {
+  if (!ctx || !c) return 1;
+  DevCamera& d = ctx->cam;
+  memcpy(d.origin, c->origin, 12); memcpy(d.lleft, c->lleft, 12); memcpy(d.horizontal, c->horizontal, 12);
+  memcpy(d.vertical, c->vertical, 12); memcpy(d.hor, c->hor, 12); memcpy(d.vert, c->vert, 12);
+  d.lensRadius = c->lensRadius;
+  d.time0 = c->time0;
+  d.time1 = c->time1;
+  ctx->haveCamera = true;
+  return 0;
+}
+
+int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
+  if (!ctx || !d) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  freeScene(ctx);
+  ctx->itemNodes.clear();
+  ctx->bvhDepth = 0;
+
+  if (validateScene(ctx, d)) return 1;
+
+  // ---- primitive records.  Device arrays are indexed by the scene's own triangle /
+  // sphere indices; the owning list index is kept for srtTraceRays' prim output.
+  std::vector<int32_t> triPrimId(d->numTriangles, -1), sphPrimId(d->numSpheres, -1);
+  for (int i = 0; i < d->numPrims; ++i) {
+    const SrtPrimRef& p = d->prims[i];
+    (p.type == SRT_PRIM_SPHERE ? sphPrimId : triPrimId)[p.index] = i;
+  }
+  std::vector<float4> triTest((size_t)d->numTriangles * 3), triShade((size_t)d->numTriangles * 4);
+  const float eps = std::numeric_limits<float>::epsilon();
+  for (int i = 0; i < d->numTriangles; ++i) {
+    const SrtTriangleIn& t = d->triangles[i];
+    H3 v0 = h3(t.p[0]), v1 = h3(t.p[1]), v2 = h3(t.p[2]);
+    H3 n = crossH(v1 - v0, v2 - v0);  // getNormal, model.h:276-283
+    triTest[3 * i + 0] = make_float4(v0.x, v0.y, v0.z, n.x);
+    triTest[3 * i + 1] = make_float4(v1.x, v1.y, v1.z, n.y);
+    triTest[3 * i + 2] = make_float4(v2.x, v2.y, v2.z, n.z);
+    H3 nu = unitH(n);  // model.h:172
+    // calcTangentBasis, model.h:214-235
+    H3 e0 = v1 - v0, e1 = v2 - v0;
+    float du0 = t.uv[1][0] - t.uv[0][0], dv0 = t.uv[1][1] - t.uv[0][1];
+    float du1 = t.uv[2][0] - t.uv[0][0], dv1 = t.uv[2][1] - t.uv[0][1];
+    float f = (du0 * dv1 - du1 * dv0);
+    if (f == 0) f += eps;
+    f = 1.0f / f;
+    H3 tg = unitH(H3{f * (dv1 * e0.x - dv0 * e1.x), f * (dv1 * e0.y - dv0 * e1.y), f * (dv1 * e0.z - dv0 * e1.z)});
+    H3 bt = unitH(H3{f * (-du1 * e0.x + du0 * e1.x), f * (-du1 * e0.y + du0 * e1.y), f * (-du1 * e0.z + du0 * e1.z)});
+    float matBits;
+    int32_t mat = t.material;
+    memcpy(&matBits, &mat, 4);
+    triShade[4 * i + 0] = make_float4(nu.x, nu.y, nu.z, t.uv[0][0]);
+    triShade[4 * i + 1] = make_float4(tg.x, tg.y, tg.z, t.uv[0][1]);
+    triShade[4 * i + 2] = make_float4(bt.x, bt.y, bt.z, t.uv[1][0]);
+    triShade[4 * i + 3] = make_float4(t.uv[1][1], t.uv[2][0], t.uv[2][1], matBits);
+  }
+  std::vector<float4> spheres((size_t)d->numSpheres * 3);
+  for (int i = 0; i < d->numSpheres; ++i) {
+    const SrtSphereIn& s = d->spheres[i];
+    bool moving = s.center0[0] != s.center1[0] || s.center0[1] != s.center1[1] || s.center0[2] != s.center1[2];
+    int32_t bits = s.material | (moving ? (1 << 30) : 0);
+    float fb;
+    memcpy(&fb, &bits, 4);
+    spheres[3 * i + 0] = make_float4(s.center0[0], s.center0[1], s.center0[2], s.radius);
+    spheres[3 * i + 1] = make_float4(s.center1[0], s.center1[1], s.center1[2], fb);
+    spheres[3 * i + 2] = make_float4(s.time0, s.time1, 0.0f, 0.0f);
+  }
+  auto devRef = [&](int32_t listRef) -> int32_t {  // ~primListIndex -> device prim ref
+    const SrtPrimRef& p = d->prims[~listRef];
+    return ~((p.index << 1) | (p.type == SRT_PRIM_SPHERE ? 1 : 0));
+  };
+
+  // ---- world: build each bvhNode (consumes the global generator in scene order)
+  std::vector<float4> nodes;
+  std::vector<int32_t> world;
+  int stackDepth = 0;
+  for (int w = 0; w < d->numWorld; ++w) {
+    const SrtWorldItem& it = d->world[w];
+    ctx->itemNodes.emplace_back();
+    if (it.kind == SRT_WORLD_PRIM) {
+      world.push_back(devRef(~it.first));
+      continue;
+    }
+    Builder b;
+    buildItem(d, it, b);
+    int32_t base = (int32_t)(nodes.size() / 2);
+    std::vector<SrtBvhNode>& hostNodes = ctx->itemNodes.back();
+    hostNodes.resize(b.nodes.size());
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+      const BuildNode& n = b.nodes[i];
+      SrtBvhNode& o = hostNodes[i];
+      memcpy(o.bmin, n.box.mn, 12);
+      memcpy(o.bmax, n.box.mx, 12);
+      o.left = n.left;
+      o.right = n.right;
+      int32_t l = n.left >= 0 ? n.left + base : devRef(n.left);
+      int32_t r = n.right >= 0 ? n.right + base : devRef(n.right);
+      float lf, rf;
+      memcpy(&lf, &l, 4);
+      memcpy(&rf, &r, 4);
+      nodes.push_back(make_float4(n.box.mn[0], n.box.mn[1], n.box.mn[2], lf));
+      nodes.push_back(make_float4(n.box.mx[0], n.box.mx[1], n.box.mx[2], rf));
+    }
+    world.push_back(base);
+    stackDepth = std::max(stackDepth, b.maxPending);
+    // tree depth for reporting: longest root->node chain
+    std::vector<int> depth(b.nodes.size(), 1);
+    for (size_t i = 0; i < b.nodes.size(); ++i) {  // pre-order: parents precede children
+      ctx->bvhDepth = std::max(ctx->bvhDepth, depth[i]);
+      if (b.nodes[i].left >= 0) depth[b.nodes[i].left] = depth[i] + 1;
+      if (b.nodes[i].right >= 0) depth[b.nodes[i].right] = depth[i] + 1;
+    }
+  }
+
+  // ---- materials / textures
+  std::vector<DevMaterial> mats(d->numMaterials);
+  for (int i = 0; i < d->numMaterials; ++i) {
+    const SrtMaterialIn& m = d->materials[i];
+    DevMaterial& o = mats[i];
+    memset(&o, 0, sizeof o);
+    o.type = m.type;
+    o.albedoTex = m.albedoTex; o.normalTex = m.normalTex; o.metallicTex = m.metallicTex; o.roughnessTex = m.roughnessTex;
+    memcpy(o.albedo, m.albedo, 16);
+    o.metalness = m.type == SRT_MAT_METAL ? (m.fuzz < 1.0f ? m.fuzz : 1.0f)  // material.h:89
+                  : m.type == SRT_MAT_DIELECTRIC ? m.ir : m.metalness;
+    o.roughness = m.roughness;
+  }
+  std::vector<DevTexture> texs(d->numTextures);
+  for (int i = 0; i < d->numTextures; ++i) {
+    const SrtTextureIn& t = d->textures[i];
+    DevTexture& o = texs[i];
+    memset(&o, 0, sizeof o);
+    o.kind = t.kind; o.width = t.width; o.height = t.height; o.bpp = t.bpp; o.offset = t.texelOffset;
+    o.even = t.even; o.odd = t.odd;
+    memcpy(o.color, t.color, 12);
+  }
+  std::vector<uint8_t> texels(d->texels, d->texels + d->numTexelBytes);
+
+  DevScene& s = ctx->scene;
+  memset(&s, 0, sizeof s);
+  if (uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
+      uploadVec(ctx, spheres, &s.spheres) || uploadVec(ctx, triPrimId, &s.triPrimId) ||
+      uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) ||
+      uploadVec(ctx, texs, &s.textures) || uploadVec(ctx, texels, &s.texels, 64))
+    return 1;
+  s.numWorld = (int32_t)world.size();
+  s.stackDepth = stackDepth;
+  ctx->haveScene = true;
+  return 0;
+}
+
+// Host-only: build world item `item` exactly as srtUploadScene does, without a device.
+int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) {
+  if (!d || !count) return 1;
+  if (validateScene(nullptr, d)) return 1;
+  if (item < 0 || item >= d->numWorld || d->world[item].kind != SRT_WORLD_BVH) return fail(nullptr, "srtBuildBvh: item %d is not a bvh", item);
+  Builder b;
+  buildItem(d, d->world[item], b);
+  *count = (int32_t)b.nodes.size();
+  if (stackDepth) *stackDepth = b.maxPending;
+  if (out) {
+    if (capacity < *count) return fail(nullptr, "srtBuildBvh: capacity too small");
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+      memcpy(out[i].bmin, b.nodes[i].box.mn, 12);
+      memcpy(out[i].bmax, b.nodes[i].box.mx, 12);
+      out[i].left = b.nodes[i].left;
+      out[i].right = b.nodes[i].right;
+    }
+  }
+  return 0;
+}
+
+int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) {
+  if (!ctx || !count) return 1;
+  if (item < 0 || item >= (int32_t)ctx->itemNodes.size()) return fail(ctx, "srtGetBvh: item %d out of range", item);
+  const auto& v = ctx->itemNodes[item];
+  *count = (int32_t)v.size();
+  if (nodes) {
+    if (capacity < (int32_t)v.size()) return fail(ctx, "srtGetBvh: capacity %d < %zu", capacity, v.size());
+    memcpy(nodes, v.data(), v.size() * sizeof(SrtBvhNode));
+  }
+  return 0;
+}
+
+int srtGetBvhDepth(SrtContext* ctx, int32_t* depth) {
+  if (!ctx || !depth) return 1;
+  *depth = ctx->bvhDepth;
+  return 0;
+}
+
+int32_t srtNumTiles(int32_t w, int32_t h) {
+  return ((w + SRT_TILE_W - 1) / SRT_TILE_W) * ((h + SRT_TILE_H - 1) / SRT_TILE_H);
+}
+int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
+  if (stride < 1) stride = 1;
+  return (srtNumTiles(w, h) + stride - 1) / stride;
+}
+
+static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
+  if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
+  if (!ctx->haveCamera) return fail(ctx, "render: no camera set");
+  if (p->imageWidth < 2 || p->imageHeight < 2) return fail(ctx, "render: image must be at least 2x2 (u,v divide by W-1,H-1)");
+  if (p->spp < 1) return fail(ctx, "render: spp must be >= 1");
+  if (p->maxBounce < 0 || p->maxBounce > SRT_MAX_BOUNCE) return fail(ctx, "render: maxBounce must be in [0,%d]", SRT_MAX_BOUNCE);
+  if (p->tileStride < 1 || p->tileFirst < 0 || p->tileFirst >= p->tileStride) return fail(ctx, "render: bad tile split %d/%d", p->tileFirst, p->tileStride);
+  if (p->sppChunks < 1 || p->sppChunks > p->spp) return fail(ctx, "render: sppChunks must be in [1, spp]");
+  return 0;
+}
+
+int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) {
+  if (!ctx || !p || !dAccumTiles) return 1;
+  if (checkParams(ctx, p)) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+  RenderArgs a;
+  memset(&a, 0, sizeof a);
+  a.scene = ctx->scene;
+  a.cam = ctx->cam;
+  a.imageWidth = p->imageWidth;
+  a.imageHeight = p->imageHeight;
+  a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
+  a.numTiles = srtNumTiles(p->imageWidth, p->imageHeight);
+  a.spp = p->spp;
+  a.maxBounce = p->maxBounce;
+  a.seed = p->seed;
+  memcpy(a.background, p->background, 12);
+  a.tMin = p->tMin;
+  a.tileFirst = p->tileFirst;
+  a.tileStride = p->tileStride;
+  a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
+  a.sppChunks = p->sppChunks;
+  a.numWork = a.numLocalTiles * a.sppChunks;
+  a.queue = ctx->dQueue;
+  a.stats = p->countStats ? ctx->dStats : nullptr;
+  const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
+  if (a.sppChunks > 1) {
+    size_t need = tileFloats4 * a.sppChunks * sizeof(float4);
+    if (ctx->chunkScratch.bytes < need) {
+      if (ctx->chunkScratch.p) HIP_OK(ctx, hipFree(ctx->chunkScratch.p));
+      ctx->chunkScratch = DeviceBuffer();
+      HIP_OK(ctx, hipMalloc(&ctx->chunkScratch.p, need));
+      ctx->chunkScratch.bytes = need;
+    }
+    a.out = static_cast<float4*>(ctx->chunkScratch.p);
+  } else {
+    a.out = static_cast<float4*>(dAccumTiles);
+  }
+  const size_t lds = ldsBytesFor(ctx, p->maxBounce);
+  if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
+  int perCU = 0;
+  if (srt_render_occupancy(p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
+  int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + 3) / 4);
+  if (grid < 1) grid = 1;
+  HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t), stream));
+  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 8 * sizeof(unsigned long long), stream));
+  HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
+  int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
+  if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+  HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
+  ctx->timed = true;
+  if (a.sppChunks > 1) {
+    rc = srt_launch_combine(a.out, (int)tileFloats4, a.sppChunks, stream);
+    if (rc) return fail(ctx, "combine launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_OK(ctx, hipMemcpyAsync(dAccumTiles, a.out, tileFloats4 * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+  }
+  return 0;
+}
+
+int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGathered, void* dRgba, void* dAccumImage,
+                    void* streamPtr) {
+  if (!ctx || !p || !dGathered) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  ResolveArgs a;
+  a.gathered = static_cast<const float4*>(dGathered);
+  a.imageWidth = p->imageWidth;
+  a.imageHeight = p->imageHeight;
+  a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
+  a.tileStride = p->tileStride < 1 ? 1 : p->tileStride;
+  a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, a.tileStride);
+  a.spp = p->spp;
+  a.rgba = static_cast<uint8_t*>(dRgba);
+  a.accumImage = static_cast<float4*>(dAccumImage);
+  int rc = srt_launch_resolve(&a, static_cast<hipStream_t>(streamPtr));
+  if (rc) return fail(ctx, "resolve launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+int srtRenderImage(SrtContext* ctx, const SrtRenderParams* pIn, float* hAccum, uint8_t* hRgba) {
+  if (!ctx || !pIn) return 1;
+  SrtRenderParams p = *pIn;
+  p.tileFirst = 0;
+  p.tileStride = 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  const size_t nPix = (size_t)p.imageWidth * p.imageHeight;
+  const size_t tileBytes = (size_t)srtNumTiles(p.imageWidth, p.imageHeight) * SRT_TILE_PIXELS * sizeof(float4);
+  void *dTiles = nullptr, *dRgba = nullptr, *dAcc = nullptr;
+  int rc = 1;
+  do {
+    if (hipMalloc(&dTiles, tileBytes) != hipSuccess) { fail(ctx, "hipMalloc tiles"); break; }
+    if (hRgba && hipMalloc(&dRgba, nPix * 4) != hipSuccess) { fail(ctx, "hipMalloc rgba"); break; }
+    if (hAccum && hipMalloc(&dAcc, nPix * sizeof(float4)) != hipSuccess) { fail(ctx, "hipMalloc accum"); break; }
+    if (srtRenderTiles(ctx, &p, dTiles, nullptr)) break;
+    if (srtResolveTiles(ctx, &p, dTiles, dRgba, dAcc, nullptr)) break;
+    if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "render kernel failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hRgba && hipMemcpy(hRgba, dRgba, nPix * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "copy rgba"); break; }
+    if (hAccum && hipMemcpy(hAccum, dAcc, nPix * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "copy accum"); break; }
+    rc = 0;
+  } while (0);
+  if (dTiles) (void)hipFree(dTiles);
+  if (dRgba) (void)hipFree(dRgba);
+  if (dAcc) (void)hipFree(dAcc);
+  return rc;
+}
+
+int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, int32_t traversal) {
+  if (!ctx || !rays || !hits || n < 0) return 1;
+  if (!ctx->haveScene) return fail(ctx, "trace: no scene uploaded");
+  if (n == 0) return 0;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  void *dRays = nullptr, *dHits = nullptr;
+  int rc = 1;
+  do {
+    if (hipMalloc(&dRays, n * sizeof(SrtRay)) != hipSuccess || hipMalloc(&dHits, n * sizeof(SrtHit)) != hipSuccess) { fail(ctx, "trace: hipMalloc"); break; }
+    if (hipMemcpy(dRays, rays, n * sizeof(SrtRay), hipMemcpyHostToDevice) != hipSuccess) { fail(ctx, "trace: copy in"); break; }
+    TraceArgs a;
+    a.scene = ctx->scene;
+    a.rays = static_cast<const SrtRay*>(dRays);
+    a.hits = static_cast<SrtHit*>(dHits);
+    a.n = n;
+    size_t lds = (size_t)std::max(ctx->scene.stackDepth, 1) * 256 * sizeof(int32_t);
+    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->prop.multiProcessorCount * 8);
+    int e = srt_launch_trace(&a, traversal, grid, lds, nullptr);
+    if (e) { fail(ctx, "trace launch failed: %s", hipGetErrorString((hipError_t)e)); break; }
+    if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "trace kernel failed"); break; }
+    if (hipMemcpy(hits, dHits, n * sizeof(SrtHit), hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "trace: copy out"); break; }
+    rc = 0;
+  } while (0);
+  if (dRays) (void)hipFree(dRays);
+  if (dHits) (void)hipFree(dHits);
+  return rc;
+}
+
+// test entry: material::scatter known answers through the kernel's own shade()
+int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13) {
+  if (!ctx || !rays || !hits || !out13 || n < 1) return 1;
+  if (!ctx->haveScene) return fail(ctx, "scatter: no scene uploaded");
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n; ++i)
+    if (hits[i].material < 0) return fail(ctx, "scatter: hit %d has no material", i);
+  void *dRays = nullptr, *dHits = nullptr, *dOut = nullptr;
+  int rc = 1;
+  do {
+    if (hipMalloc(&dRays, n * sizeof(SrtRay)) != hipSuccess || hipMalloc(&dHits, n * sizeof(SrtHit)) != hipSuccess ||
+        hipMalloc(&dOut, (size_t)n * 13 * 4) != hipSuccess) { fail(ctx, "scatter: hipMalloc"); break; }
+    (void)hipMemcpy(dRays, rays, n * sizeof(SrtRay), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dHits, hits, n * sizeof(SrtHit), hipMemcpyHostToDevice);
+    int e = srt_launch_scatter(&ctx->scene, (const SrtRay*)dRays, (const SrtHit*)dHits, (float*)dOut, seed, n, nullptr);
+    if (e) { fail(ctx, "scatter launch failed"); break; }
+    if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "scatter kernel failed"); break; }
+    (void)hipMemcpy(out13, dOut, (size_t)n * 13 * 4, hipMemcpyDeviceToHost);
+    rc = 0;
+  } while (0);
+  if (dRays) (void)hipFree(dRays);
+  if (dHits) (void)hipFree(dHits);
+  if (dOut) (void)hipFree(dOut);
+  return rc;
+}
+
+int srtLastKernelMs(SrtContext* ctx, float* ms) {
+  if (!ctx || !ms) return 1;
+  if (!ctx->timed) return fail(ctx, "no render has been launched");
+  HIP_OK(ctx, hipEventSynchronize(ctx->evStop));
+  HIP_OK(ctx, hipEventElapsedTime(ms, ctx->evStart, ctx->evStop));
+  return 0;
+}
+
+int srtGetStats(SrtContext* ctx, SrtStats* out) {
+  if (!ctx || !out) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  HIP_OK(ctx, hipDeviceSynchronize());
+  unsigned long long v[8];
+  HIP_OK(ctx, hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost));
+  out->samples = v[0]; out->rays = v[1]; out->nodeVisits = v[2]; out->boxPasses = v[3];
+  out->triTests = v[4]; out->sphereTests = v[5]; out->shadedTriHits = v[6]; out->texelFetches = v[7];
+  return 0;
+}
+
+int srtDeviceInfo(SrtContext* ctx, char* name, int32_t nameCap, int32_t* numCUs, int32_t* clockMHz) {
+  if (!ctx) return 1;
+  if (name && nameCap > 0) {
+    snprintf(name, nameCap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (numCUs) *numCUs = ctx->prop.multiProcessorCount;
+  if (clockMHz) *clockMHz = ctx->prop.clockRate / 1000;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,789 @@
+// srt_kernels.hip -- the per-pixel path-tracing loop as hand-written HIP for gfx950 (MI355X).
+//
+// Replaces main.cpp:200-227 (pixel/sample loop), camera::getRay (camera.h:40-46),
+// rayColor (main.cpp:33-52), hittableList/bvhNode/sphere/triangle::hit
+// (hittablelist.h:33-47, bvh.h:97-105, sphere.h:54-83, model.h:104-181), the four
+// material::scatter bodies (material.h:91-97,108-126,144-150,156-245), pbr.h:58-81,
+// texture::value (texture.h:26-28,42-48,129-148) and writeColorTarget (color.h:25-41).
+//
+// Execution model (CDNA4):
+//   * one wavefront (64 lanes) owns one 8x8 pixel tile; lane = pixel.  Waves are
+//     persistent and pull (tile, sample-chunk) work items from an atomic counter,
+//     so long tiles (ground, mesh) and short tiles (sky) balance across the 256 CUs.
+//   * a lane runs its pixel's samples in index order and adds them in that order
+//     (main.cpp:204-218), so accumulators are reproducible bit for bit and
+//     independent of tiling / GPU count.  When a lane's path ends it immediately
+//     generates its next camera ray ("path regeneration"), so every traversal
+//     step has all unfinished lanes active regardless of bounce depth.
+//   * bounce recursion is a loop; the per-bounce attenuations sit in a small
+//     per-lane LDS stack and are folded innermost-first at path end, which
+//     reproduces the recursion's rounding (E + A*(E' + A'*(...))) exactly.
+//   * BVH traversal is a per-lane DFS in the reference's fixed left-then-right
+//     order with the pending right children on a per-lane LDS stack laid out
+//     [slot][thread] (bank = thread: conflict-free), "while-while" shaped so
+//     box tests and primitive tests are each executed by converged lanes.
+//   * RNG: PCG32 keyed by (seed, pixel, sample) per lane.
+//   * all arithmetic keeps the reference's operation order; built with
+//     -ffp-contract=off; divisions and sqrt are IEEE (hipcc default).
+// No MFMA: there is no dense contraction on this path.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "srt_device.h"
+
+#define SRT_BLOCK 256
+
+namespace {
+
+// ------------------------------------------------------------------ vectors
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// Eigen 3-vector dot: x*x' + (y*y' + z*z')
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vec3.h:29-31: (x*x + y*y) + z*z
+__device__ __forceinline__ float lenSq(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+__device__ __forceinline__ float dist3(V3 a, V3 b) { return sqrtf(lenSq(a - b)); }  // vec3.h:37-39
+__device__ __forceinline__ V3 unitv(V3 v) {                                           // vec3.h:54-60
+  float len = sqrtf(lenSq(v));
+  if (len != 0) return mk(v.x / len, v.y / len, v.z / len);
+  return v;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {  // globals.h:17-24
+  if (x < lo) return lo;
+  if (x > hi) return hi;
+  return x;
+}
+__device__ __forceinline__ V3 reflect3(V3 v, V3 n) { return v - (2.0f * dot3(v, n)) * n; }  // vec3.h:76-78
+
+#define SRT_EPS 1.1920928955078125e-07f /* FLT_EPSILON, globals.h:14 */
+#define SRT_PI 3.14159274101257324f     /* float(3.1415926535897932385), globals.h:15 */
+#define SRT_INF __builtin_inff()
+
+// ------------------------------------------------------------------ RNG
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct Pcg {
+  uint64_t state;
+  __device__ __forceinline__ void key(uint64_t seedMixed, uint32_t pixel, uint32_t sample) {
+    state = mix64(seedMixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+  }
+  __device__ __forceinline__ uint32_t bits() {
+    uint64_t old = state;
+    state = old * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((32u - rot) & 31u));
+  }
+  // globals.h:30-35 as libstdc++ evaluates it: float(u32) * 2^-32, clamped below 1
+  __device__ __forceinline__ float uniform() {
+    float r = (float)bits() * 2.3283064365386963e-10f;
+    return r >= 1.0f ? 0x1.fffffep-1f : r;
+  }
+  __device__ __forceinline__ float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }  // globals.h:37-39
+  // vec3.h:62-70 with vec3.h:45-47's g++ argument order (z, y, x)
+  __device__ __forceinline__ V3 inUnitSphere() {
+    while (true) {
+      float z = uniform(-1.0f, 1.0f);
+      float y = uniform(-1.0f, 1.0f);
+      float x = uniform(-1.0f, 1.0f);
+      V3 p = mk(x, y, z);
+      if (lenSq(p) >= 1.0f) continue;
+      return p;
+    }
+  }
+  __device__ __forceinline__ void inUnitDisk(float& x, float& y) {  // vec3.h:88-95 (y first)
+    while (true) {
+      y = uniform(-1.0f, 1.0f);
+      x = uniform(-1.0f, 1.0f);
+      if ((x * x + y * y) + 0.0f * 0.0f >= 1.0f) continue;
+      return;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ rays, hits
+struct Ray {
+  V3 o, d;
+  float time;
+};
+
+struct Counters {
+  uint32_t nodeVisits, boxPasses, triTests, sphereTests;
+};
+
+// ------------------------------------------------------------------ geometry tests
+// aabb.h:11-27.  tMin only grows and tMax only shrinks through the three axes, so the
+// per-axis early outs collapse to one final comparison.
+__device__ __forceinline__ bool boxHit(float4 n0, float4 n1, const Ray& r, float tMin, float tMax) {
+  float a, b;
+  a = (n0.x - r.o.x) / r.d.x;
+  b = (n1.x - r.o.x) / r.d.x;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = (n0.y - r.o.y) / r.d.y;
+  b = (n1.y - r.o.y) / r.d.y;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = (n0.z - r.o.z) / r.d.z;
+  b = (n1.z - r.o.z) / r.d.z;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  return !(tMax <= tMin);
+}
+
+// sphere.h:47-52
+__device__ __forceinline__ V3 sphereCenter(const float4* sp, float4 s0, float4 s1, float time) {
+  V3 c0 = mk(s0.x, s0.y, s0.z);
+  if (__float_as_int(s1.w) & (1 << 30)) {
+    float4 s2 = sp[2];
+    V3 c1 = mk(s1.x, s1.y, s1.z);
+    return c0 + ((time - s2.x) / (s2.y - s2.x)) * (c1 - c0);
+  }
+  return c0;
+}
+
+// sphere.h:54-73: returns the root, or NaN-free miss flag
+__device__ __forceinline__ bool sphereHit(const float4* sp, const Ray& r, float a, float tMin, float tMax, float& tOut) {
+  float4 s0 = sp[0], s1 = sp[1];
+  V3 oc = r.o - sphereCenter(sp, s0, s1, r.time);
+  float halfB = dot3(oc, r.d);
+  float c = lenSq(oc) - s0.w * s0.w;
+  float disc = halfB * halfB - a * c;
+  if (disc < 0.0f) return false;
+  float sqrtd = sqrtf(disc);
+  float root = (-halfB - sqrtd) / a;
+  if (root < tMin || root > tMax) {
+    root = (-halfB + sqrtd) / a;
+    if (root < tMin || root > tMax) return false;
+  }
+  tOut = root;
+  return true;
+}
+
+// model.h:104-154.  n is precomputed on the host with the same operation order as
+// getNormal (model.h:276-283).  CLOSEST adds the t > tMax rejection the reference lacks.
+template <bool CLOSEST>
+__device__ __forceinline__ bool triHit(const float4* tr, const Ray& r, float tMin, float tMax, float& tOut) {
+  float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+  V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
+  V3 n = mk(q0.w, q1.w, q2.w);
+  float NdotDir = dot3(n, r.d);
+  if (fabsf(NdotDir) < SRT_EPS) return false;
+  if (NdotDir > 0) return false;  // dot(dir, n) has the same bits as dot(n, dir)
+  float d = -dot3(n, v0);
+  float t = -(dot3(n, r.o) + d) / NdotDir;
+  if (t < tMin) return false;
+  if (CLOSEST && t > tMax) return false;
+  V3 p = r.o + t * r.d;
+  V3 c;
+  c = cross3(v1 - v0, p - v0);
+  if (dot3(n, c) < 0) return false;
+  c = cross3(v2 - v1, p - v1);
+  if (dot3(n, c) < 0) return false;
+  c = cross3(v0 - v2, p - v2);
+  if (dot3(n, c) < 0) return false;
+  tOut = t;
+  return true;
+}
+
+// hittableList::hit over the world list (hittablelist.h:33-47) with bvhNode::hit
+// (bvh.h:97-105) as an explicit DFS.  In the reference the tMax handed to any node or
+// primitive is "the t of the most recent successful primitive hit, else the caller's
+// tMax" (by induction over bvh.h:102-103), i.e. one running value `closest`.
+// A single-object leaf (left == right, bvh.h:67-69) tests its object twice with
+// identical outcome; it is tested once here.
+template <bool CLOSEST, bool COUNT>
+__device__ __forceinline__ int traverse(const DevScene& sc, const Ray& r, float tMin, float tMax, int32_t* stack,
+                                        float& tHit, Counters& cnt) {
+  const float a = lenSq(r.d);  // sphere.h:56, per ray
+  float closest = tMax;
+  int hitRef = SRT_REF_DONE;
+  for (int w = 0; w < sc.numWorld; ++w) {
+    int cur = sc.world[w];
+    int sp = 0;
+    while (true) {
+      while (cur >= 0) {
+        float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+        if (COUNT) cnt.nodeVisits++;
+        if (boxHit(n0, n1, r, tMin, closest)) {
+          if (COUNT) cnt.boxPasses++;
+          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          if (right != left) {
+            stack[sp * SRT_BLOCK] = right;
+            sp++;
+          }
+          cur = left;
+        } else {
+          if (sp == 0) {
+            cur = SRT_REF_DONE;
+            break;
+          }
+          sp--;
+          cur = stack[sp * SRT_BLOCK];
+        }
+      }
+      if (cur == SRT_REF_DONE) break;
+      int pr = ~cur;
+      float t;
+      bool ok;
+      if (pr & 1) {
+        if (COUNT) cnt.sphereTests++;
+        ok = sphereHit(sc.spheres + 3 * (pr >> 1), r, a, tMin, closest, t);
+      } else {
+        if (COUNT) cnt.triTests++;
+        ok = triHit<CLOSEST>(sc.triTest + 3 * (pr >> 1), r, tMin, closest, t);
+      }
+      if (ok) {
+        closest = t;
+        hitRef = cur;
+      }
+      if (sp == 0) break;
+      sp--;
+      cur = stack[sp * SRT_BLOCK];
+    }
+  }
+  tHit = closest;
+  return hitRef;
+}
+
+// ------------------------------------------------------------------ hit record (hittable.h:9-22)
+struct Record {
+  V3 p, normal, tangent, bitangent;
+  float u, v, t;
+  bool frontFace;
+  int material;
+  bool isTri;
+};
+
+__device__ __forceinline__ void setFaceNormal(Record& rec, const Ray& r, V3 outward) {  // hittable.h:18-21
+  rec.frontFace = dot3(r.d, outward) < 0;
+  rec.normal = rec.frontFace ? outward : -outward;
+}
+
+__device__ __forceinline__ void sphereRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec) {
+  const float4* sp = sc.spheres + 3 * idx;
+  float4 s0 = sp[0], s1 = sp[1];
+  rec.t = t;
+  rec.p = r.o + t * r.d;                                                  // ray.h:15-17
+  V3 outward = unitv(rec.p - sphereCenter(sp, s0, s1, r.time));           // sphere.h:76
+  setFaceNormal(rec, r, outward);
+  float theta = acosf(-outward.y);                                        // sphere.h:32-38
+  float phi = atan2f(-outward.z, outward.x) + SRT_PI;
+  rec.u = phi / (2.0f * SRT_PI);
+  rec.v = theta / SRT_PI;
+  rec.material = __float_as_int(s1.w) & 0x3fffffff;
+  rec.isTri = false;
+  // sphere.h:96-106; dot(n, UnitY) = n.x*0 + (n.y*1 + n.z*0)
+  float ny = outward.x * 0.0f + (outward.y * 1.0f + outward.z * 0.0f);
+  V3 b = (1.0f - fabsf(ny) < SRT_EPS) ? mk(-0.0f, -0.0f, -1.0f) : mk(0.0f, 1.0f, 0.0f);
+  rec.tangent = unitv(cross3(b, outward));
+  rec.bitangent = unitv(cross3(outward, rec.tangent));
+}
+
+__device__ __forceinline__ void triRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec) {
+  const float4* tr = sc.triTest + 3 * idx;
+  const float4* sh = sc.triShade + 4 * idx;
+  float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+  float4 h0 = sh[0], h1 = sh[1], h2 = sh[2], h3 = sh[3];
+  V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
+  V3 p = r.o + t * r.d;
+  // inverse-distance weights (model.h:158-169)
+  float d0 = dist3(p, v0), d1 = dist3(p, v1), d2 = dist3(p, v2);
+  float denom = (1.0f / d0) + (1.0f / d1) + (1.0f / d2);
+  float r0 = (1.0f / d0) / denom, r1 = (1.0f / d1) / denom, r2 = (1.0f / d2) / denom;
+  rec.u = r0 * h0.w + r1 * h2.w + r2 * h3.y;
+  rec.v = 1.0f - (r0 * h1.w + r1 * h3.x + r2 * h3.z);
+  rec.t = t;
+  rec.p = p;
+  setFaceNormal(rec, r, mk(h0.x, h0.y, h0.z));  // unitVector(normal) precomputed (model.h:172)
+  rec.tangent = mk(h1.x, h1.y, h1.z);          // calcTangentBasis precomputed (model.h:214-235)
+  rec.bitangent = mk(h2.x, h2.y, h2.z);
+  rec.material = __float_as_int(h3.w);
+  rec.isTri = true;
+}
+
+// ------------------------------------------------------------------ textures (texture.h)
+template <bool COUNT>
+__device__ __forceinline__ V3 texLeaf(const DevScene& sc, int id, float u, float v, uint32_t& fetches) {
+  const DevTexture& t = sc.textures[id];
+  if (t.kind == SRT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);  // texture.h:26-28
+  // imagePNG::value, texture.h:129-148
+  if (t.width == 0) return mk(1.0f, 0.0f, 1.0f);
+  if (COUNT) fetches++;
+  u = clampf(u, 0.0f, 1.0f);
+  v = 1.0f - clampf(v, 0.0f, 1.0f);
+  int i = (int)(u * (float)t.width);
+  int j = (int)(v * (float)t.height);
+  if (!(u == u)) i = 0;  // NaN uv: UB in the reference, defined as texel 0 here and in the oracle
+  if (!(v == v)) j = 0;
+  if (i >= t.width) i = t.width - 1;
+  if (j >= t.height) j = t.height - 1;
+  const uint8_t* px = sc.texels + t.offset + (int64_t)j * (t.bpp * t.width) + (int64_t)i * t.bpp;
+  return mk((float)px[0], (float)px[1], (float)px[2]);  // bpp==1: the next two texels (texture.h:147)
+}
+
+template <bool COUNT>
+__device__ __forceinline__ V3 texValue(const DevScene& sc, int id, float u, float v, V3 p, uint32_t& fetches) {
+  const DevTexture& t = sc.textures[id];
+  if (t.kind == SRT_TEX_CHECKER) {  // texture.h:42-48
+    float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+    int child = (sines < 0) ? t.odd : t.even;
+    return texLeaf<COUNT>(sc, child, u, v, fetches) * 255.0f;
+  }
+  return texLeaf<COUNT>(sc, id, u, v, fetches);
+}
+
+// ------------------------------------------------------------------ pbr.h
+__device__ __forceinline__ float trowbridgeReitzNDF(float NdotH, float roughness) {  // pbr.h:58-65
+  float alpha = roughness * roughness;
+  float alpha2 = alpha * alpha;
+  float NdotH2 = NdotH * NdotH;
+  float b = NdotH2 * (alpha2 - 1.0f) + 1.0f;
+  float denom = SRT_PI * (b * b);  // std::pow(b, 2.0f) == b*b correctly rounded
+  return alpha2 / denom;
+}
+__device__ __forceinline__ float schlickGAF(float NdotV, float roughness) {  // pbr.h:69-73
+  float k = ((roughness + 1.0f) * (roughness + 1.0f)) / 8.0f;
+  return NdotV / (NdotV * (1.0f - k) + k);
+}
+
+// ------------------------------------------------------------------ materials
+// returns false when the path ends here (scatter == false); emitted is always set.
+template <bool COUNT>
+__device__ __forceinline__ bool shade(const DevScene& sc, const Ray& rIn, const Record& rec, Pcg& rng, V3& att,
+                                      Ray& out, V3& emitted, uint32_t& fetches) {
+  const DevMaterial& m = sc.materials[rec.material];
+  emitted = mk(0.0f, 0.0f, 0.0f);  // material.h:18-20
+  out.o = rec.p;
+  out.time = rIn.time;
+  switch (m.type) {
+    case SRT_MAT_LIGHT: {  // material.h:144-150
+      emitted = texValue<COUNT>(sc, m.albedoTex, rec.u, rec.v, rec.p, fetches);
+      return false;
+    }
+    case SRT_MAT_METAL: {  // material.h:91-97
+      V3 reflected = reflect3(unitv(rIn.d), rec.normal);
+      V3 fz = rng.inUnitSphere();  // drawn even when fuzz == 0
+      out.d = reflected + m.metalness * fz;
+      att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+      return dot3(out.d, rec.normal) > 0;
+    }
+    case SRT_MAT_DIELECTRIC: {  // material.h:108-136
+      att = mk(1.0f, 1.0f, 1.0f);
+      float ir = m.metalness;
+      float ratio = rec.frontFace ? (1.0f / ir) : ir;
+      V3 unitDir = unitv(rIn.d);
+      float cosTheta = fminf(dot3(rec.normal, -unitDir), 1.0f);  // double fmin of floats is exact
+      float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+      bool reflectIt = ratio * sinTheta > 1.0f;
+      if (!reflectIt) {
+        // reflectance (material.h:132-136): double pow(x, 5), expression in double, narrowed
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 = r0 * r0;
+        double x = (double)(1.0f - cosTheta);
+        double x2 = x * x;
+        double x5 = x2 * x2 * x;
+        float refl = (float)((double)r0 + (double)(1.0f - r0) * x5);
+        reflectIt = refl > rng.uniform();
+      }
+      if (reflectIt) {
+        out.d = reflect3(unitDir, rec.normal);
+      } else {  // refract, vec3.h:80-86
+        float ct = fminf(dot3(rec.normal, -unitDir), 1.0f);
+        V3 perp = ratio * (unitDir + ct * rec.normal);
+        V3 par = (-sqrtf(fabsf(1.0f - lenSq(perp)))) * rec.normal;
+        out.d = perp + par;
+      }
+      return true;
+    }
+    default: {  // pbrMetallicRoughness::scatter, material.h:156-245
+      V3 a0;
+      if (m.albedoTex >= 0)
+        a0 = texValue<COUNT>(sc, m.albedoTex, rec.u, rec.v, rec.p, fetches) / 255.0f;
+      else
+        a0 = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+      V3 normal;
+      if (m.normalTex >= 0) {
+        V3 nt = texValue<COUNT>(sc, m.normalTex, rec.u, rec.v, rec.p, fetches);
+        nt = mk(nt.x - 128.0f, nt.y - 128.0f, nt.z - 128.0f) / 128.0f;  // vec3.h:103-110
+        // Matrix3f(T|B|N) * nt, each row reduced x + (y + z)
+        V3 w = mk(rec.tangent.x * nt.x + (rec.bitangent.x * nt.y + rec.normal.x * nt.z),
+                  rec.tangent.y * nt.x + (rec.bitangent.y * nt.y + rec.normal.y * nt.z),
+                  rec.tangent.z * nt.x + (rec.bitangent.z * nt.y + rec.normal.z * nt.z));
+        normal = unitv(w);
+      } else
+        normal = rec.normal;
+      float mt, rg;
+      if (m.metallicTex >= 0)
+        mt = clampf(texValue<COUNT>(sc, m.metallicTex, rec.u, rec.v, rec.p, fetches).x / 255.0f, 0.0f, 1.0f);
+      else
+        mt = m.metalness;
+      if (m.roughnessTex >= 0)
+        rg = clampf(texValue<COUNT>(sc, m.roughnessTex, rec.u, rec.v, rec.p, fetches).y / 255.0f, 0.0f, 1.0f);
+      else
+        rg = m.roughness;
+
+      V3 sd = normal + unitv(rng.inUnitSphere());  // randomUnitVector, vec3.h:72-74
+      // nearZero (vec3.h:49-52): float |x| compared against the DOUBLE 1e-8
+      if ((double)fabsf(sd.x) < 1e-8 && (double)fabsf(sd.y) < 1e-8 && (double)fabsf(sd.z) < 1e-8) sd = normal;
+      sd = unitv(sd);
+      out.d = sd;
+      V3 viewVec = -unitv(rIn.d);
+      V3 halfVec = unitv(sd + viewVec);
+      float NdotL = fmaxf(dot3(normal, sd), 0.0f);
+      float NdotH = fmaxf(dot3(normal, halfVec), 0.0f);
+      float HdotV = fmaxf(dot3(halfVec, viewVec), 0.0f);
+      float NdotV = fmaxf(dot3(normal, viewVec), 0.0f);
+      V3 fr = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+      // lerp(0.4, fr, mt), vec3.h:97-101.  F0 for dielectrics is 0.4 (material.h:228)
+      V3 F0 = mk((1.0f - mt) * 0.4f + mt * fr.x, (1.0f - mt) * 0.4f + mt * fr.y, (1.0f - mt) * 0.4f + mt * fr.z);
+      float D = trowbridgeReitzNDF(NdotH, rg);
+      // fresnelEpic (pbr.h:75-81): pow(2.0f, x) resolves to the double pow, narrowed to float
+      float power = (float)exp2((double)((-5.55473f * HdotV - 6.98316f) * HdotV));
+      V3 F = mk(F0.x + (1.0f - F0.x) * power, F0.y + (1.0f - F0.y) * power, F0.z + (1.0f - F0.z) * power);
+      float G = schlickGAF(NdotL, rg) * schlickGAF(NdotV, rg);
+      V3 fd = a0 / SRT_PI;
+      fd = mk(fd.x * (1.0f - F.x), fd.y * (1.0f - F.y), fd.z * (1.0f - F.z));
+      fd = fd * (1.0f - mt);
+      fd = mk(fd.x * m.albedo[0], fd.y * m.albedo[1], fd.z * m.albedo[2]);
+      V3 fs = ((D * F) * G) / (4.0f * NdotV * NdotL + SRT_EPS);
+      att = (fd + fs) * NdotL;
+      return true;
+    }
+  }
+}
+
+// camera::getRay, camera.h:40-46
+__device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, Pcg& rng, Ray& r) {
+  float dx, dy;
+  rng.inUnitDisk(dx, dy);
+  // rd = lensRadius * p;  offset = rd.x * hor + rd.y * vert
+  float rx = c.lensRadius * dx, ry = c.lensRadius * dy;
+  V3 offset = rx * ld3(c.hor) + ry * ld3(c.vert);
+  V3 origin = ld3(c.origin);
+  r.o = origin + offset;
+  r.d = ld3(c.lleft) + s * ld3(c.horizontal) + t * ld3(c.vertical) - origin - offset;
+  r.time = rng.uniform(c.time0, c.time1);
+}
+
+}  // namespace
+
+// =================================================================== render
+// main.cpp:200-227 for the tiles of this rank.
+template <bool CLOSEST, bool COUNT>
+__global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs a) {
+  extern __shared__ int32_t lds[];
+  // per-thread LDS slots, [slot][thread]: stackDepth traversal slots, then 3*maxBounce attenuation floats
+  int32_t* stack = lds + threadIdx.x;
+  float* attStack = reinterpret_cast<float*>(lds + a.scene.stackDepth * SRT_BLOCK + threadIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int lx = lane & (SRT_TILE_W - 1), ly = lane >> 3;
+  const uint64_t seedMixed = mix64(a.seed);
+  const V3 background = ld3(a.background);
+
+  unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
+
+  while (true) {
+    int work = 0;
+    if (lane == 0) work = atomicAdd(a.queue, 1);
+    work = __builtin_amdgcn_readfirstlane(work);
+    if (work >= a.numWork) break;
+    const int chunk = work / a.numLocalTiles;
+    const int localTile = work - chunk * a.numLocalTiles;
+    const int tile = a.tileFirst + localTile * a.tileStride;
+    float4 result = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int px = tx * SRT_TILE_W + lx, py = ty * SRT_TILE_H + ly;
+    // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
+    int s = (int)(((long long)a.spp * chunk) / a.sppChunks);
+    const int sEnd = (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
+    bool alive = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && s < sEnd;
+    const uint32_t pixel = (uint32_t)(py * a.imageWidth + px);
+
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    Ray ray;
+    Pcg rng;
+    int depth = 0;
+    bool needNew = true;
+    while (__any(alive)) {
+      if (alive) {
+        if (needNew) {
+          rng.key(seedMixed, pixel, (uint32_t)s);
+          float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                       // main.cpp:210
+          float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);   // main.cpp:211
+          cameraRay(a.cam, u, v, rng, ray);
+          depth = 0;
+          needNew = false;
+          if (COUNT) cSamples++;
+        }
+        // rayColor, main.cpp:33-52, one bounce
+        Counters cnt = {0, 0, 0, 0};
+        float tHit;
+        if (COUNT) cRays++;
+        int ref = traverse<CLOSEST, COUNT>(a.scene, ray, a.tMin, SRT_INF, stack, tHit, cnt);
+        if (COUNT) {
+          cNodes += cnt.nodeVisits;
+          cBox += cnt.boxPasses;
+          cTri += cnt.triTests;
+          cSph += cnt.sphereTests;
+        }
+        V3 terminal;
+        bool done;
+        if (ref == SRT_REF_DONE) {
+          terminal = background;  // main.cpp:39-40
+          done = true;
+        } else {
+          Record rec;
+          int pr = ~ref;
+          if (pr & 1)
+            sphereRecord(a.scene, pr >> 1, ray, tHit, rec);
+          else
+            triRecord(a.scene, pr >> 1, ray, tHit, rec);
+          V3 att, emitted;
+          Ray next;
+          uint32_t fetches = 0;
+          if (COUNT && rec.isTri) cShTri++;
+          bool scattered = shade<COUNT>(a.scene, ray, rec, rng, att, next, emitted, fetches);
+          if (COUNT) cTex += fetches;
+          if (!scattered) {
+            terminal = emitted;  // main.cpp:46-47
+            done = true;
+          } else {
+            // emitted is (0,0,0) for every scattering material (material.h:18-20)
+            attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
+            attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
+            attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
+            ray = next;
+            depth++;
+            done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
+            terminal = mk(0.0f, 0.0f, 0.0f);
+          }
+        }
+        if (done) {
+          // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
+          V3 L = terminal;
+          for (int j = depth - 1; j >= 0; --j) {
+            float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
+                  az = attStack[(3 * j + 2) * SRT_BLOCK];
+            L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
+          }
+          acc = acc + L;  // main.cpp:217
+          s++;
+          needNew = true;
+          alive = s < sEnd;
+        }
+      }
+    }
+    result = make_float4(acc.x, acc.y, acc.z, (float)(sEnd - (int)(((long long)a.spp * chunk) / a.sppChunks)));
+    // tile-major output: one coalesced 1 KiB store per wave
+    a.out[((size_t)chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + lane] = result;
+  }
+
+  if (COUNT && a.stats) {
+    unsigned long long v[8] = {cSamples, cRays, cNodes, cBox, cTri, cSph, cShTri, cTex};
+    for (int k = 0; k < 8; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+      if (lane == 0) atomicAdd(&a.stats[k], x);
+    }
+  }
+}
+
+// combine sample chunks in chunk order: out[0][i] = sum_c out[c][i]
+__global__ void srt_combine_chunks_kernel(float4* buf, int n, int chunks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 acc = buf[i];
+  for (int c = 1; c < chunks; ++c) {
+    float4 v = buf[(size_t)c * n + i];
+    acc.x += v.x;
+    acc.y += v.y;
+    acc.z += v.z;
+    acc.w += v.w;
+  }
+  buf[i] = acc;
+}
+
+// =================================================================== resolve (color.h:25-41)
+__global__ void srt_resolve_kernel(const ResolveArgs a) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.imageWidth * a.imageHeight) return;
+  int x = idx % a.imageWidth, y = idx / a.imageWidth;
+  int tile = (y / SRT_TILE_H) * a.tilesX + (x / SRT_TILE_W);
+  int lane = (y % SRT_TILE_H) * SRT_TILE_W + (x % SRT_TILE_W);
+  int rank = tile % a.tileStride, local = tile / a.tileStride;
+  float4 v = a.gathered[((size_t)rank * a.numLocalTiles + local) * SRT_TILE_PIXELS + lane];
+  if (a.accumImage) a.accumImage[idx] = v;
+  if (a.rgba) {
+    float scale = 1.0f / (float)a.spp;
+    float c[3] = {v.x, v.y, v.z};
+    uint8_t o[4];
+    for (int k = 0; k < 3; ++k) {
+      float g = sqrtf(c[k] * scale);
+      float q = 256.0f * clampf(g, 0.0f, 0.999f);
+      o[k] = (q == q) ? (uint8_t)q : (uint8_t)0;  // NaN -> 0 (what the reference's UB cast yields on x86)
+    }
+    o[3] = 255;
+    reinterpret_cast<uchar4*>(a.rgba)[idx] = make_uchar4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// =================================================================== fixed ray set
+template <bool CLOSEST>
+__global__ __launch_bounds__(SRT_BLOCK) void srt_trace_kernel(const TraceArgs a) {
+  extern __shared__ int32_t lds[];
+  int32_t* stack = lds + threadIdx.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+    SrtRay in = a.rays[i];
+    Ray r;
+    r.o = ld3(in.o);
+    r.d = ld3(in.d);
+    r.time = in.time;
+    Counters cnt = {0, 0, 0, 0};
+    float tHit;
+    int ref = traverse<CLOSEST, true>(a.scene, r, in.tMin, in.tMax, stack, tHit, cnt);
+    SrtHit h;
+    h.prim = SRT_NO_HIT;
+    h.t = 0;
+    for (int k = 0; k < 3; ++k) h.p[k] = h.normal[k] = h.tangent[k] = h.bitangent[k] = 0;
+    h.uv[0] = h.uv[1] = 0;
+    h.frontFace = 0;
+    h.material = -1;
+    if (ref != SRT_REF_DONE) {
+      Record rec;
+      int pr = ~ref;
+      if (pr & 1) {
+        sphereRecord(a.scene, pr >> 1, r, tHit, rec);
+        h.prim = a.scene.sphPrimId[pr >> 1];
+      } else {
+        triRecord(a.scene, pr >> 1, r, tHit, rec);
+        h.prim = a.scene.triPrimId[pr >> 1];
+      }
+      h.t = rec.t;
+      h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
+      h.normal[0] = rec.normal.x; h.normal[1] = rec.normal.y; h.normal[2] = rec.normal.z;
+      h.tangent[0] = rec.tangent.x; h.tangent[1] = rec.tangent.y; h.tangent[2] = rec.tangent.z;
+      h.bitangent[0] = rec.bitangent.x; h.bitangent[1] = rec.bitangent.y; h.bitangent[2] = rec.bitangent.z;
+      h.uv[0] = rec.u; h.uv[1] = rec.v;
+      h.frontFace = rec.frontFace ? 1 : 0;
+      h.material = rec.material;
+    }
+    h.nodeVisits = (int)cnt.nodeVisits;
+    h.boxPasses = (int)cnt.boxPasses;
+    h.triTests = (int)cnt.triTests;
+    h.sphereTests = (int)cnt.sphereTests;
+    a.hits[i] = h;
+  }
+}
+
+// material scatter known-answer kernel: one shade() per entry (tests only drive it
+// through srtScatterTest; same device function the render kernel uses)
+struct ScatterArgs {
+  DevScene scene;
+  const SrtRay* rays;
+  const SrtHit* hits;
+  float* out;  // 13 floats per entry
+  uint64_t seed;
+  int n;
+};
+__global__ void srt_scatter_kernel(const ScatterArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  Ray r;
+  r.o = ld3(a.rays[i].o);
+  r.d = ld3(a.rays[i].d);
+  r.time = a.rays[i].time;
+  const SrtHit& h = a.hits[i];
+  Record rec;
+  rec.p = ld3(h.p); rec.normal = ld3(h.normal); rec.tangent = ld3(h.tangent); rec.bitangent = ld3(h.bitangent);
+  rec.u = h.uv[0]; rec.v = h.uv[1]; rec.t = h.t; rec.frontFace = h.frontFace != 0; rec.material = h.material;
+  rec.isTri = false;
+  Pcg rng;
+  rng.key(mix64(a.seed), (uint32_t)i, 0u);
+  V3 att = mk(0, 0, 0), em;
+  Ray out;
+  out.d = mk(0, 0, 0);
+  uint32_t fetches = 0;
+  bool ok = shade<false>(a.scene, r, rec, rng, att, out, em, fetches);
+  float* o = a.out + 13 * i;
+  o[0] = att.x; o[1] = att.y; o[2] = att.z;
+  o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z;
+  o[6] = out.o.x; o[7] = out.o.y; o[8] = out.o.z;
+  o[9] = ok ? 1.0f : 0.0f;
+  o[10] = em.x; o[11] = em.y; o[12] = em.z;
+}
+
+// =================================================================== launch wrappers (host)
+extern "C" {
+
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
+  dim3 g(grid), b(SRT_BLOCK);
+  if (traversal == SRT_TRAVERSE_CLOSEST) {
+    if (count)
+      hipLaunchKernelGGL((srt_render_kernel<true, true>), g, b, ldsBytes, stream, *a);
+    else
+      hipLaunchKernelGGL((srt_render_kernel<true, false>), g, b, ldsBytes, stream, *a);
+  } else {
+    if (count)
+      hipLaunchKernelGGL((srt_render_kernel<false, true>), g, b, ldsBytes, stream, *a);
+    else
+      hipLaunchKernelGGL((srt_render_kernel<false, false>), g, b, ldsBytes, stream, *a);
+  }
+  return (int)hipGetLastError();
+}
+
+int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU) {
+  hipError_t e;
+  if (traversal == SRT_TRAVERSE_CLOSEST)
+    e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<true, true>, SRT_BLOCK, ldsBytes)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<true, false>, SRT_BLOCK, ldsBytes);
+  else
+    e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<false, true>, SRT_BLOCK, ldsBytes)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<false, false>, SRT_BLOCK, ldsBytes);
+  return (int)e;
+}
+
+int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_combine_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, buf, n, chunks);
+  return (int)hipGetLastError();
+}
+
+int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream) {
+  int n = a->imageWidth * a->imageHeight;
+  hipLaunchKernelGGL(srt_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *a);
+  return (int)hipGetLastError();
+}
+
+int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream) {
+  if (traversal == SRT_TRAVERSE_CLOSEST)
+    hipLaunchKernelGGL(srt_trace_kernel<true>, dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, *a);
+  else
+    hipLaunchKernelGGL(srt_trace_kernel<false>, dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, *a);
+  return (int)hipGetLastError();
+}
+
+int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
+                       hipStream_t stream) {
+  ScatterArgs a{*sc, rays, hits, out, seed, n};
+  hipLaunchKernelGGL(srt_scatter_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""ctypes binding of csrc/libsrt_hip.so, the C-ABI library declared in include/srt_hip.h.
+
+Importing this module loads the HIP extension and raises if it is not built: there is
+no CPU fallback for the hot path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsrt_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("HIP extension not built: %s is missing (run __graft_entry__.build() or "
+                      "`make -C sexy-raytracer_amd/csrc`)" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
+           "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles",
+           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest",
+           "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
+
+_vp = C.c_void_p
+lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
+lib.srtDestroy.argtypes = [_vp]
+lib.srtLastError.argtypes = [_vp]
+lib.srtLastError.restype = C.c_char_p
+lib.srtMakeCamera.argtypes = [C.POINTER(abi.SrtCameraParams), C.POINTER(abi.SrtCamera)]
+lib.srtHostRandomFloat.restype = C.c_float
+lib.srtHostRandomReset.restype = None
+lib.srtUploadScene.argtypes = [_vp, C.POINTER(abi.SrtSceneDesc)]
+lib.srtSetCamera.argtypes = [_vp, C.POINTER(abi.SrtCamera)]
+lib.srtBuildBvh.argtypes = [C.POINTER(abi.SrtSceneDesc), C.c_int32, _vp, C.c_int32, C.POINTER(C.c_int32),
+                            C.POINTER(C.c_int32)]
+lib.srtGetBvh.argtypes = [_vp, C.c_int32, _vp, C.c_int32, C.POINTER(C.c_int32)]
+lib.srtGetBvhDepth.argtypes = [_vp, C.POINTER(C.c_int32)]
+lib.srtNumTiles.argtypes = [C.c_int32, C.c_int32]
+lib.srtNumTiles.restype = C.c_int32
+lib.srtNumLocalTiles.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+lib.srtNumLocalTiles.restype = C.c_int32
+lib.srtRenderTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
+lib.srtResolveTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _vp, _vp]
+lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
+lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
+lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
+lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
+lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
+lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+
+
+class SrtError(RuntimeError):
+    pass
+
+
+def make_camera(params):
+    """camera ctor arithmetic (camera.h:10-38) on the host; needs no GPU."""
+    cam = abi.SrtCamera()
+    if lib.srtMakeCamera(C.byref(params), C.byref(cam)):
+        raise SrtError("srtMakeCamera failed")
+    return cam
+
+
+def host_random_reset():
+    lib.srtHostRandomReset()
+
+
+def host_random_float():
+    return float(lib.srtHostRandomFloat())
+
+
+def num_tiles(w, h):
+    return int(lib.srtNumTiles(w, h))
+
+
+def num_local_tiles(w, h, stride):
+    return int(lib.srtNumLocalTiles(w, h, stride))
+
+
+def build_bvh_host(scene_builder, item=0, reset_rng=True):
+    """bvh.h:55-95 on the host, no GPU: returns (nodes, traversal stack depth)."""
+    desc = scene_builder.desc()
+    n, sd = C.c_int32(0), C.c_int32(0)
+    if reset_rng:
+        host_random_reset()
+    if lib.srtBuildBvh(C.byref(desc), item, None, 0, C.byref(n), C.byref(sd)):
+        raise SrtError("srtBuildBvh failed")
+    if reset_rng:  # the sizing call consumed generator draws: rebuild from the same state
+        host_random_reset()
+    nodes = np.zeros(n.value, abi.NODE_DTYPE)
+    if lib.srtBuildBvh(C.byref(desc), item, nodes.ctypes.data, n.value, C.byref(n), C.byref(sd)):
+        raise SrtError("srtBuildBvh failed")
+    return nodes, sd.value
+
+
+class Context:
+    """One per GPU (glDevice's role, gl.h:16-40)."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        if lib.srtCreate(device, C.byref(h)):
+            raise SrtError("srtCreate(%d) failed: no usable HIP device" % device)
+        self.h = h
+        self._scene_keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.srtDestroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise SrtError(lib.srtLastError(self.h).decode())
+
+    def upload_scene(self, scene_builder, reset_rng=True):
+        """reset_rng: start from the fresh process-global generator, as a new process of the
+        reference would (globals.h:31-32)."""
+        if reset_rng:
+            host_random_reset()
+        desc = scene_builder.desc()
+        self._scene_keep = (scene_builder, desc)
+        self._check(lib.srtUploadScene(self.h, C.byref(desc)))
+
+    def set_camera(self, cam):
+        self._check(lib.srtSetCamera(self.h, C.byref(cam)))
+
+    def bvh(self, item=0):
+        n = C.c_int32(0)
+        self._check(lib.srtGetBvh(self.h, item, None, 0, C.byref(n)))
+        nodes = np.zeros(n.value, abi.NODE_DTYPE)
+        self._check(lib.srtGetBvh(self.h, item, nodes.ctypes.data, n.value, C.byref(n)))
+        return nodes
+
+    def bvh_depth(self):
+        d = C.c_int32(0)
+        self._check(lib.srtGetBvhDepth(self.h, C.byref(d)))
+        return d.value
+
+    def render_image(self, params, want_accum=True, want_rgba=True):
+        W, H = params.imageWidth, params.imageHeight
+        accum = np.zeros((H, W, 4), np.float32) if want_accum else None
+        rgba = np.zeros((H, W, 4), np.uint8) if want_rgba else None
+        self._check(lib.srtRenderImage(self.h, C.byref(params), accum.ctypes.data if want_accum else None,
+                                       rgba.ctypes.data if want_rgba else None))
+        return accum, rgba
+
+    def render_tiles(self, params, d_accum_ptr, stream=None):
+        self._check(lib.srtRenderTiles(self.h, C.byref(params), d_accum_ptr, stream))
+
+    def resolve_tiles(self, params, d_gathered_ptr, d_rgba_ptr=None, d_accum_image_ptr=None, stream=None):
+        self._check(lib.srtResolveTiles(self.h, C.byref(params), d_gathered_ptr, d_rgba_ptr, d_accum_image_ptr, stream))
+
+    def trace(self, rays, traversal=abi.SRT_TRAVERSE_FAITHFUL):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        hits = np.zeros(len(rays), abi.HIT_DTYPE)
+        self._check(lib.srtTraceRays(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, traversal))
+        return hits
+
+    def scatter_test(self, rays, hits, seed):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        hits = np.ascontiguousarray(hits, abi.HIT_DTYPE)
+        out = np.zeros((len(rays), 13), np.float32)
+        self._check(lib.srtScatterTest(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), seed, out.ctypes.data))
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(lib.srtLastKernelMs(self.h, C.byref(ms)))
+        return ms.value
+
+    def stats(self):
+        s = abi.SrtStats()
+        self._check(lib.srtGetStats(self.h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in s._fields_}
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mhz = C.c_int32(0), C.c_int32(0)
+        self._check(lib.srtDeviceInfo(self.h, name, 256, C.byref(cus), C.byref(mhz)))
+        return {"name": name.value.decode(), "cus": cus.value, "clock_mhz": mhz.value}

@@ -1,0 +1,154 @@
+"""The BASELINE.json configs as concrete scenes, built in the
+reference's construction order so BVH sort ties and RNG draws line up with
+main.cpp:54-154.  Returns SceneBuilder objects (abi.py)."""
+import os
+
+import numpy as np
+
+from .abi import SceneBuilder
+from .gltf import load_gltf
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+_png_cache = {}
+
+
+def _load_png(path, bpp):
+    """stbi_load(path, ..., req_comp=bpp) (texture.h:115): 8-bit RGB or L bytes."""
+    from PIL import Image
+    key = (path, bpp)
+    if key not in _png_cache:
+        im = Image.open(path).convert("RGB" if bpp == 3 else "L")
+        a = np.asarray(im, dtype=np.uint8)
+        _png_cache[key] = a.reshape(a.shape[0], a.shape[1], bpp)
+    return _png_cache[key]
+
+
+def _ground(sb):
+    # main.cpp:89-90; pbr ctor material.h:29-32 leaves metalness/roughness
+    # uninitialised: defined as 0, 0.
+    chk = sb.checker((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))
+    return sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=chk, metalness=0.0, roughness=0.0))
+
+
+def _smooth_noise(rng, h, w, octaves):
+    """Deterministic tileable value noise in [0,1]."""
+    out = np.zeros((h, w), np.float64)
+    amp, total = 1.0, 0.0
+    for o in octaves:
+        g = rng.random((max(2, h // o), max(2, w // o)))
+        ys = (np.arange(h) / o) % g.shape[0]
+        xs = (np.arange(w) / o) % g.shape[1]
+        y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+        y1, x1 = (y0 + 1) % g.shape[0], (x0 + 1) % g.shape[1]
+        fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+        fy, fx = fy * fy * (3 - 2 * fy), fx * fx * (3 - 2 * fx)
+        v = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x1] * (1 - fy) * fx
+             + g[y1][:, x0] * fy * (1 - fx) + g[y1][:, x1] * fy * fx)
+        out += amp * v
+        total += amp
+        amp *= 0.5
+    return out / total
+
+
+def iron_textures(seed=2, w=1024, h=512):
+    """Seeded procedural stand-ins for rustediron2_{basecolor,normal,metallic,roughness}-2x1.png
+    (main.cpp:133-136), which are missing blobs in the reference (.MISSING_LARGE_BLOBS:1-6).
+    Returns (albedo RGB, normal RGB, metallic L, roughness L) uint8 arrays."""
+    rng = np.random.default_rng(seed)
+    rust = _smooth_noise(rng, h, w, (64, 32, 16, 8, 4))
+    fine = _smooth_noise(rng, h, w, (8, 4, 2))
+    mask = np.clip((rust - 0.48) * 6.0, 0.0, 1.0)  # 1 = rust, 0 = bare metal
+    metal_col = np.array([0.56, 0.57, 0.58])
+    rust_col = np.array([0.45, 0.22, 0.12])
+    alb = (metal_col[None, None, :] * (1 - mask[..., None]) + rust_col[None, None, :] * mask[..., None])
+    alb = alb * (0.75 + 0.5 * fine[..., None])
+    albedo = np.clip(alb * 255.0, 0, 255).astype(np.uint8)
+    hgt = rust * 0.7 + fine * 0.3
+    dx = np.roll(hgt, -1, 1) - np.roll(hgt, 1, 1)
+    dy = np.roll(hgt, -1, 0) - np.roll(hgt, 1, 0)
+    n = np.stack([-dx * 24.0, -dy * 24.0, np.ones_like(dx)], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    normal = np.clip(n * 127.5 + 127.5, 0, 255).astype(np.uint8)
+    metallic = np.clip((1 - mask) * 255.0, 0, 255).astype(np.uint8)[..., None]
+    roughness = np.clip((0.25 + 0.6 * mask + 0.15 * fine) * 255.0, 0, 255).astype(np.uint8)[..., None]
+    return albedo, normal, metallic, roughness
+
+
+def _iron_sphere(sb, seed=2):
+    # main.cpp:133-141: pbr ctor material.h:47-52 (albedo factor 1,1,1,1; m=r=0 unused: maps present)
+    a, n, m, r = iron_textures(seed)
+    mat = sb.pbr(albedo_tex=sb.image(a, 3), normal_tex=sb.image(n, 3), metallic_tex=sb.image(m, 1),
+                 roughness_tex=sb.image(r, 1), albedo=(1.0, 1.0, 1.0, 1.0), metalness=0.0, roughness=0.0)
+    return sb.add_sphere((-3.0, 1.0, 0.0), 1.0, mat)
+
+
+def scene_spheres():
+    """Configs C1/C2: ground + three unit spheres (diffuse pbr / dielectric 1.5 / metal fuzz 0),
+    positions and materials from main.cpp:90,124-125,140-144; wrapped in one bvhNode (main.cpp:146)."""
+    sb = SceneBuilder()
+    _ground(sb)
+    sb.add_sphere((-3.0, 1.0, 0.0), 1.0, sb.pbr(albedo_tex=sb.solid(0.4 * 255, 0.2 * 255, 0.1 * 255),
+                                                  metalness=0.0, roughness=0.0))
+    sb.add_sphere((0.0, 1.0, 0.0), 1.0, sb.dielectric(1.5))
+    sb.add_sphere((3.0, 1.0, 0.0), 1.0, sb.metal((0.7, 0.6, 0.5), 0.0))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+def scene_iron():
+    """Config C3: ground + PBR textured sphere (normal map + metallic/roughness maps)."""
+    sb = SceneBuilder()
+    _ground(sb)
+    _iron_sphere(sb)
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+def add_masterchief(sb, gltf_path=None):
+    """model::create(...)->init() then objects.add(every triangle) (main.cpp:74-86)."""
+    gltf_path = gltf_path or os.path.join(ASSETS, "masterchief2-separate-xf.gltf")
+    for prim in load_gltf(gltf_path):
+        m = prim["material"]
+        # model.h:420-437: three imagePNG(…, 3); the metallicRoughness map is stored but never
+        # sampled (material.h:190-200), so metallic/roughness come from the scalar factors.
+        alb = sb.image(_load_png(m["albedo"], 3), 3) if m["albedo"] else -1
+        nrm = sb.image(_load_png(m["normal"], 3), 3) if m["normal"] else -1
+        mat = sb.pbr(albedo_tex=alb, normal_tex=nrm, albedo=m["baseColorFactor"],
+                     metalness=m["metallicFactor"], roughness=m["roughnessFactor"])
+        sb.add_triangles(prim["positions"], prim["texcoords"], prim["indices"], mat)
+
+
+def scene_masterchief(with_spheres=True):
+    """Config C4/C5: the main.cpp HEAD scene (main.cpp:54-154): masterchief mesh (3042 triangles),
+    ground, light sphere, iron sphere, metal sphere -> 3046 prims in one bvhNode."""
+    sb = SceneBuilder()
+    add_masterchief(sb)
+    _ground(sb)
+    if with_spheres:
+        sb.add_sphere((-7.0, 4.0, 6.0), 1.0, sb.light((250.2, 220.9, 110.2)))  # main.cpp:126-127
+        _iron_sphere(sb)
+        sb.add_sphere((3.0, 1.0, 0.0), 1.0, sb.metal((0.7, 0.6, 0.5), 0.0))    # main.cpp:143-144
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+def scene_soup(num_triangles, seed=7, extent=6.0, size=0.08, with_ground=True):
+    """Synthetic seeded triangle soup (SURVEY 8d 'Synthetic'): working sets beyond the caches."""
+    rng = np.random.default_rng(seed)
+    sb = SceneBuilder()
+    c = (rng.random((num_triangles, 1, 3), dtype=np.float32) - 0.5) * np.float32(2 * extent)
+    c[..., 1] = c[..., 1] * 0.5 + np.float32(extent * 0.5)
+    v = c + (rng.random((num_triangles, 3, 3), dtype=np.float32) - 0.5) * np.float32(2 * size)
+    pos = v.reshape(-1, 3)
+    uv = rng.random((num_triangles * 3, 2), dtype=np.float32)
+    idx = np.arange(num_triangles * 3, dtype=np.int32).reshape(-1, 3)
+    mat = sb.pbr(albedo_tex=sb.solid(0.7 * 255, 0.6 * 255, 0.5 * 255), metalness=0.0, roughness=0.5)
+    sb.add_triangles(pos, uv, idx, mat)
+    if with_ground:
+        _ground(sb)
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+SCENES = {"spheres": scene_spheres, "iron": scene_iron, "masterchief": scene_masterchief}

@@ -1,0 +1,201 @@
+"""GPU tests through the C-ABI at BASELINE sizes via size-independent properties, plus the edge
+cases of the domain (ragged tiles, no-BVH worlds, single-object leaves, moving spheres, missing
+textures, the 1-bpp texel quirk, bounce limits) and the boundary's error behaviour."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_tiles_all_ranks(ctx, dev, abi, p, nranks):
+    """Renders every rank's tile share one after another on the one GPU and gathers them the
+    way dist.gather would (rank-major), then resolves on the device."""
+    import torch
+    W, H = p.imageWidth, p.imageHeight
+    nloc = dev.num_local_tiles(W, H, nranks)
+    gathered = torch.zeros((nranks, nloc, 64, 4), dtype=torch.float32, device="cuda")
+    for r in range(nranks):
+        p.tileFirst, p.tileStride = r, nranks
+        ctx.render_tiles(p, gathered[r].data_ptr(), None)
+    rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    p.tileStride = nranks
+    ctx.resolve_tiles(p, gathered.data_ptr(), rgba.data_ptr(), accum.data_ptr(), None)
+    torch.cuda.synchronize()
+    return accum.cpu().numpy(), rgba.cpu().numpy()
+
+
+def test_720p_tile_split_invariance_and_determinism(ctx, dev, abi, srt, camera):
+    """BASELINE 720p (configs 2-4 geometry) on the main.cpp scene: the image is bit-identical for
+    1/2/3/8-way interleaved tile splits (SURVEY 8e invariant) and across repeated runs."""
+    ctx.upload_scene(srt.scenes.scene_masterchief())
+    ctx.set_camera(camera)
+    p = abi.default_render_params(1280, 720, 4, 4, seed=31)
+    ref_acc, ref_rgba = ctx.render_image(p)
+    crc = zlib.crc32(ref_acc.tobytes())
+    for n in (1, 2, 3, 8):
+        acc, rgba = _render_tiles_all_ranks(ctx, dev, abi, abi.default_render_params(1280, 720, 4, 4, seed=31), n)
+        assert zlib.crc32(acc.tobytes()) == crc, n
+        assert np.array_equal(rgba, ref_rgba)
+    # sky rows are pure background: sqrt-gamma of (0.53,0.81,0.92) -> 186,230,245, alpha 255
+    assert (ref_rgba[:40, :, :] == np.array([186, 230, 245, 255])).all()
+    assert (ref_acc[..., 3] == 4).all()
+
+
+def test_sample_sum_linearity(ctx, abi, srt, camera):
+    """Samples are keyed by (pixel, sample index): a chunked render equals the sequential one up to
+    the re-association of the per-pixel sum, and chunks=spp still visits every sample once."""
+    ctx.upload_scene(srt.scenes.scene_spheres())
+    ctx.set_camera(camera)
+    p = abi.default_render_params(426, 240, 32, 8, seed=8)
+    seq, _ = ctx.render_image(p)
+    for chunks in (2, 5, 32):
+        p.sppChunks = chunks
+        ch, _ = ctx.render_image(p)
+        assert (ch[..., 3] == 32).all()
+        np.testing.assert_allclose(ch[..., :3], seq[..., :3], rtol=2e-5, atol=1e-6)
+    p.sppChunks = 1
+    # different seed -> different image, same statistics
+    p.seed = 9
+    other, _ = ctx.render_image(p)
+    assert not np.array_equal(other, seq)
+    assert abs(other[..., :3].mean() - seq[..., :3].mean()) < 0.01 * seq[..., :3].mean()
+
+
+def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
+    sb = srt.scenes.scene_spheres()
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    for (w, h) in ((9, 9), (2, 2), (17, 5), (426, 3)):
+        p = abi.default_render_params(w, h, 3, 8, seed=4)
+        acc, rgba = ctx.render_image(p)
+        want, want_rgba, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=2)
+        bit = (acc.view(np.uint32) == want.view(np.uint32)).all(axis=-1)
+        assert bit.mean() >= 0.97 and np.allclose(acc, want, rtol=1e-3, atol=1e-6)
+        assert np.abs(rgba.astype(int) - want_rgba.astype(int)).max() <= 1
+
+
+def test_bounce_limits(ctx, abi, srt, camera):
+    ctx.upload_scene(srt.scenes.scene_spheres())
+    ctx.set_camera(camera)
+    p = abi.default_render_params(64, 36, 2, 0, seed=1)
+    acc, rgba = ctx.render_image(p)  # main.cpp:36-37: no bounces -> black, nothing traced
+    assert (acc[..., :3] == 0).all() and (rgba[..., :3] == 0).all() and (rgba[..., 3] == 255).all()
+    p.maxBounce = 1  # only misses (background) and lights contribute
+    acc, _ = ctx.render_image(p)
+    bg = np.array([0.53, 0.81, 0.92], np.float32)
+    px = acc[..., :3] / 2
+    is_bg = np.isclose(px, bg).all(axis=-1)
+    is_black = (px == 0).all(axis=-1)
+    assert (is_bg | is_black | np.isclose(px, bg / 2).all(axis=-1)).all() and is_bg.any() and is_black.any()
+
+
+def _world_variants(abi):
+    def three(sb):
+        m1, m2 = sb.metal((0.8, 0.7, 0.6), 0.2), sb.dielectric(1.5)
+        sb.add_sphere((0.0, 2.0, 0.0), 1.0, m1)
+        sb.add_sphere((-2.2, 2.0, 0.0), 1.0, m2)
+        sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=sb.checker((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))
+    out = {}
+    sb = abi.SceneBuilder(); three(sb)
+    for i in range(3):
+        sb.world_prim(i)            # plain hittableList, no BVH (main.cpp:153 `return objects`)
+    out["list"] = sb
+    sb = abi.SceneBuilder(); three(sb)
+    sb.world_bvh(0, 1); sb.world_bvh(1, 2)   # span-1 leaf (left == right) + span-2 node, two roots
+    out["two_bvh"] = sb
+    sb = abi.SceneBuilder()
+    m = sb.metal((0.7, 0.6, 0.5), 0.0)
+    rng = np.random.default_rng(12)
+    for _ in range(23):             # moving spheres, sphere.h:47-52
+        c = rng.uniform(-3, 3, 3) + np.array([0, 3, -1])
+        sb.add_sphere(tuple(c), 0.4, m, center1=tuple(c + rng.uniform(-0.4, 0.4, 3)), time0=0.0, time1=1.0)
+    sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=sb.solid(120.0, 130.0, 140.0), roughness=0.4))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    out["moving"] = sb
+    sb = abi.SceneBuilder()
+    tex = np.arange(7 * 5, dtype=np.uint8).reshape(5, 7, 1) * 7
+    missing = sb.image(None, 3)     # failed load -> (1,0,1), texture.h:130-131
+    onebpp = sb.image(tex, 1)       # roughness reads pixel[1] = next texel, overrun at the end (texture.h:147)
+    rgb = sb.image((np.arange(6 * 4 * 3, dtype=np.uint8).reshape(4, 6, 3) * 3), 3)
+    sb.add_sphere((0.0, 2.0, 0.0), 1.5, sb.pbr(albedo_tex=missing, metallic_tex=onebpp, roughness_tex=onebpp))
+    sb.add_sphere((3.0, 2.0, 0.0), 1.0, sb.pbr(albedo_tex=rgb, normal_tex=rgb, albedo=(0.9, 0.8, 0.7, 1.0), metalness=0.3, roughness=0.6))
+    sb.add_sphere((-3.5, 3.0, 1.0), 0.7, sb.light((4.0, 3.0, 2.0)))
+    sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=sb.checker((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    out["textures"] = sb
+    return out
+
+
+@pytest.mark.parametrize("variant", ["list", "two_bvh", "moving", "textures"])
+def test_world_and_material_variants_vs_oracle(ctx, oracle, abi, camera, variant):
+    sb = _world_variants(abi)[variant]
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    p = abi.default_render_params(160, 90, 8, 6, seed=77, count_stats=1)
+    acc, rgba = ctx.render_image(p)
+    st = ctx.stats()
+    want, want_rgba, want_st = osc.render(camera, p, oracle.RNG_COUNTER, threads=4)
+    assert np.array_equal(np.isnan(acc), np.isnan(want))
+    bit = (acc.view(np.uint32) == want.view(np.uint32)).all(axis=-1)
+    assert bit.mean() >= 0.995, bit.mean()
+    ok = np.isnan(want) | (np.abs(acc - want) <= 1e-3 * np.maximum(np.abs(want), 1e-3))
+    assert ok.all()
+    assert np.abs(rgba.astype(int) - want_rgba.astype(int)).max() <= 1
+    for k in ("samples", "rays", "nodeVisits", "boxPasses", "triTests", "sphereTests", "texelFetches"):
+        assert st[k] == want_st[k], k
+
+
+def test_soup_scene_trace_and_render(ctx, oracle, abi, srt, camera):
+    """Synthetic 20k-triangle soup (deeper tree, degenerate slivers): bit-exact trace, close render."""
+    sb = srt.scenes.scene_soup(20000, seed=3)
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    assert ctx.bvh(0).tobytes() == osc.bvh(0)[0].tobytes()
+    rng = np.random.default_rng(2)
+    rays = np.zeros(20000, abi.RAY_DTYPE)
+    rays["o"] = (0.0, 3.0, 5.0)
+    rays["d"] = rng.normal(size=(len(rays), 3)).astype(np.float32)
+    rays["tMin"], rays["tMax"] = 0.001, np.inf
+    want, got = osc.trace(rays), ctx.trace(rays)
+    assert np.array_equal(got["prim"], want["prim"])
+    m = want["prim"] >= 0
+    assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
+    for f in ("nodeVisits", "boxPasses", "triTests", "sphereTests"):
+        assert np.array_equal(got[f], want[f])
+    p = abi.default_render_params(160, 90, 4, 4, seed=6)
+    acc, _ = ctx.render_image(p)
+    wacc, _, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=8, want_stats=False)
+    bit = (acc.view(np.uint32) == wacc.view(np.uint32)).all(axis=-1)
+    assert bit.mean() >= 0.995
+
+
+def test_error_behaviour(dev, abi, srt, camera):
+    """int return codes + text from srtLastError, never an exception or a silent fallback."""
+    c = dev.Context(0)
+    p = abi.default_render_params(64, 36, 1, 4)
+    with pytest.raises(dev.SrtError, match="no scene"):
+        c.render_image(p)
+    sb = srt.scenes.scene_spheres()
+    c.upload_scene(sb)
+    with pytest.raises(dev.SrtError, match="no camera"):
+        c.render_image(p)
+    c.set_camera(camera)
+    for field, bad in (("spp", 0), ("maxBounce", 99), ("imageWidth", 1), ("sppChunks", 0)):
+        q = abi.default_render_params(64, 36, 1, 4)
+        setattr(q, field, bad)
+        with pytest.raises(dev.SrtError):
+            c.render_image(q)
+    d = srt.scenes.scene_spheres().desc()
+    d.materials[0].albedoTex = 1234
+    assert dev.lib.srtUploadScene(c.h, C.byref(d)) != 0
+    assert b"texture id" in dev.lib.srtLastError(c.h)
+    h = C.c_void_p()
+    assert dev.lib.srtCreate(4096, C.byref(h)) != 0
+    c.close()

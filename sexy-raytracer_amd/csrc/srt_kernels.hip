@@ -514,7 +514,8 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
     // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
     int s = (int)(((long long)a.spp * chunk) / a.sppChunks);
     const int sEnd = (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
-    bool alive = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && s < sEnd;
+    // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
+    bool alive = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && s < sEnd && a.maxBounce > 0;
     const uint32_t pixel = (uint32_t)(py * a.imageWidth + px);
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);

@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC passes for the render kernel (separate rocprofv3 runs per counter group; never combined with tracing).
+# usage: tools/pmc_run.sh <outdir> <bench args...>
+set -o pipefail
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" \
+           "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$out/pmc$i" -- python3 bench.py "$@" --no-cpu-baseline > "$out/pmc$i.log" 2>&1 || echo "pass $i failed"
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "srt_render_kernel" not in k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
+with open(out + "/pmc_summary.csv", "w") as fo:
+    fo.write("kernel,counter,dispatches,sum,per_dispatch\n")
+    for k in agg:
+        for c in sorted(agg[k]):
+            fo.write('"%s",%s,%d,%.6g,%.6g\n' % (k, c, calls[k][c], agg[k][c], agg[k][c] / calls[k][c]))
+print(open(out + "/pmc_summary.csv").read())
+PY

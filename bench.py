@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--workload", default="masterchief_720p_5000spp", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (0 = the workload's)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--spp-chunks", type=int, default=8,
+                    help="work items per pixel: samples of a pixel are summed in index order inside a chunk and the "
+                         "chunk sums in chunk order (1 = the reference's single running sum, main.cpp:217)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--save-png", default="")
@@ -140,7 +143,9 @@ def main():
     nloc = dev.num_local_tiles(W, H, world)
     local = torch.zeros((nloc, 64, 4), dtype=torch.float32, device="cuda")
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
-    params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world)
+    chunks = max(1, min(args.spp_chunks, spp))
+    params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
+                                       spp_chunks=chunks)
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms = []
 
@@ -204,7 +209,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (assets/masterchief2 mesh + seeded procedural iron textures)",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": spp,
-                       "max_bounce": max_bounce, "seed": args.seed, "traversal": "faithful (bvh.h order)",
+                       "max_bounce": max_bounce, "seed": args.seed, "spp_chunks": chunks, "traversal": "faithful (bvh.h order)",
                        "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

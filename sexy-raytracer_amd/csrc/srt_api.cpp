@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -248,6 +249,11 @@ void freeScene(SrtContext* ctx) {
   ctx->haveScene = false;
 }
 
+int envInt(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
   return (size_t)(ctx->scene.stackDepth + 3 * maxBounce) * 256 * sizeof(int32_t);
 }
@@ -291,6 +297,7 @@ int validateScene(SrtContext* ctx, const SrtSceneDesc* d) {
     int lim = p.type == SRT_PRIM_SPHERE ? d->numSpheres : p.type == SRT_PRIM_TRIANGLE ? d->numTriangles : -1;
     if (p.index < 0 || p.index >= lim) return fail(ctx, "prim %d: bad type/index", i);
   }
+  if (d->numWorld < 1) return fail(ctx, "scene has an empty world list");
   for (int w = 0; w < d->numWorld; ++w) {
     const SrtWorldItem& it = d->world[w];
     if (it.first < 0 || it.count < 1 || it.first + it.count > d->numPrims || (it.kind != SRT_WORLD_PRIM && it.kind != SRT_WORLD_BVH))
@@ -598,7 +605,9 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.tileStride = p->tileStride;
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
   a.sppChunks = p->sppChunks;
-  a.numWork = a.numLocalTiles * a.sppChunks;
+  a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
+  a.shadeMin = envInt("SRT_SHADE_MIN", 24);
+  a.primMin = envInt("SRT_PRIM_MIN", 20);
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
@@ -619,7 +628,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   int perCU = 0;
   if (srt_render_occupancy(p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
-  int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + 3) / 4);
+  int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t), stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 8 * sizeof(unsigned long long), stream));

@@ -487,6 +487,18 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 
 // =================================================================== render
 // main.cpp:200-227 for the tiles of this rank.
+//
+// Every lane is an independent persistent worker: it pulls a work item (one pixel x one
+// sample chunk) from a global counter, runs that pixel's samples in index order, writes the
+// partial sum and pulls the next item.  A lane is always in exactly one of three states --
+// at a BVH node, at a primitive, or at a shading point (path vertex / new camera ray / new
+// work item) -- and each trip round the wave's loop executes ONE kind of step for the lanes
+// that are in that state, chosen by ballot counts.  Box tests, primitive tests and shading
+// are therefore each executed by a well-filled wave although the 64 paths are at different
+// depths of different trees (the reference's 1.74 rays/sample x 55 node visits/ray vary by
+// two orders of magnitude from ray to ray).
+enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3 };
+
 template <bool CLOSEST, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
@@ -494,107 +506,204 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
   int32_t* stack = lds + threadIdx.x;
   float* attStack = reinterpret_cast<float*>(lds + a.scene.stackDepth * SRT_BLOCK + threadIdx.x);
   const int lane = threadIdx.x & 63;
-  const int lx = lane & (SRT_TILE_W - 1), ly = lane >> 3;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
+  const DevScene& sc = a.scene;
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
 
-  while (true) {
-    int work = 0;
-    if (lane == 0) work = atomicAdd(a.queue, 1);
-    work = __builtin_amdgcn_readfirstlane(work);
-    if (work >= a.numWork) break;
-    const int chunk = work / a.numLocalTiles;
-    const int localTile = work - chunk * a.numLocalTiles;
-    const int tile = a.tileFirst + localTile * a.tileStride;
-    float4 result = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-    const int px = tx * SRT_TILE_W + lx, py = ty * SRT_TILE_H + ly;
-    // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
-    int s = (int)(((long long)a.spp * chunk) / a.sppChunks);
-    const int sEnd = (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
-    // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
-    bool alive = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && s < sEnd && a.maxBounce > 0;
-    const uint32_t pixel = (uint32_t)(py * a.imageWidth + px);
+  // ---- lane state
+  int mode = M_SHADE;
+  bool hasRay = false;   // a finished traversal (hitRef, closest) is waiting to be shaded
+  int s = 0, sEnd = 0;   // samples [s, sEnd) of the current work item remain
+  int sCount = 0, outIndex = -1;
+  int px = 0, py = 0;
+  uint32_t pixel = 0;
+  V3 acc = mk(0.0f, 0.0f, 0.0f);
+  Ray ray;
+  ray.o = ray.d = mk(0.0f, 0.0f, 0.0f);
+  ray.time = 0.0f;
+  Pcg rng;
+  rng.state = 0;
+  int depth = 0;
+  // traversal state (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
+  int cur = SRT_REF_DONE, sp = 0, w = 0, hitRef = SRT_REF_DONE;
+  float closest = SRT_INF, rayA = 0.0f;
 
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
-    Ray ray;
-    Pcg rng;
-    int depth = 0;
-    bool needNew = true;
-    while (__any(alive)) {
-      if (alive) {
-        if (needNew) {
-          rng.key(seedMixed, pixel, (uint32_t)s);
-          float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                       // main.cpp:210
-          float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);   // main.cpp:211
-          cameraRay(a.cam, u, v, rng, ray);
-          depth = 0;
-          needNew = false;
-          if (COUNT) cSamples++;
-        }
-        // rayColor, main.cpp:33-52, one bounce
-        Counters cnt = {0, 0, 0, 0};
-        float tHit;
-        if (COUNT) cRays++;
-        int ref = traverse<CLOSEST, COUNT>(a.scene, ray, a.tMin, SRT_INF, stack, tHit, cnt);
-        if (COUNT) {
-          cNodes += cnt.nodeVisits;
-          cBox += cnt.boxPasses;
-          cTri += cnt.triTests;
-          cSph += cnt.sphereTests;
-        }
-        V3 terminal;
-        bool done;
-        if (ref == SRT_REF_DONE) {
-          terminal = background;  // main.cpp:39-40
-          done = true;
+  // next pending reference after the current subtree is done; ends the traversal when none is left
+  auto popNext = [&]() {
+    if (sp > 0) {
+      sp--;
+      cur = stack[sp * SRT_BLOCK];
+    } else if (++w < sc.numWorld) {
+      cur = sc.world[w];
+    } else {
+      cur = SRT_REF_DONE;
+    }
+    mode = (cur == SRT_REF_DONE) ? M_SHADE : (cur >= 0 ? M_NODE : M_PRIM);
+    if (cur == SRT_REF_DONE) hasRay = true;
+  };
+
+  for (;;) {
+    const unsigned long long mN = __ballot(mode == M_NODE), mP = __ballot(mode == M_PRIM),
+                             mS = __ballot(mode == M_SHADE);
+    const int nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS);
+    if ((nN | nP | nS) == 0) break;
+    int pick;
+    if (nS >= a.shadeMin || (nN | nP) == 0)
+      pick = M_SHADE;
+    else if (nP >= a.primMin || nN == 0)
+      pick = M_PRIM;
+    else
+      pick = M_NODE;
+    pick = __builtin_amdgcn_readfirstlane(pick);
+
+    if (pick == M_NODE) {
+      // ------------------------------------------------ bvhNode::hit, bvh.h:97-105
+      if (mode == M_NODE) {
+        float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+        if (COUNT) cNodes++;
+        if (boxHit(n0, n1, ray, a.tMin, closest)) {
+          if (COUNT) cBox++;
+          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          if (right != left) {
+            stack[sp * SRT_BLOCK] = right;
+            sp++;
+          }
+          cur = left;
+          mode = cur >= 0 ? M_NODE : M_PRIM;
         } else {
-          Record rec;
-          int pr = ~ref;
-          if (pr & 1)
-            sphereRecord(a.scene, pr >> 1, ray, tHit, rec);
-          else
-            triRecord(a.scene, pr >> 1, ray, tHit, rec);
-          V3 att, emitted;
-          Ray next;
-          uint32_t fetches = 0;
-          if (COUNT && rec.isTri) cShTri++;
-          bool scattered = shade<COUNT>(a.scene, ray, rec, rng, att, next, emitted, fetches);
-          if (COUNT) cTex += fetches;
-          if (!scattered) {
-            terminal = emitted;  // main.cpp:46-47
+          popNext();
+        }
+      }
+    } else if (pick == M_PRIM) {
+      // ------------------------------------------------ sphere::hit / triangle::hit
+      if (mode == M_PRIM) {
+        int pr = ~cur;
+        float t;
+        bool ok;
+        if (pr & 1) {
+          if (COUNT) cSph++;
+          ok = sphereHit(sc.spheres + 3 * (pr >> 1), ray, rayA, a.tMin, closest, t);
+        } else {
+          if (COUNT) cTri++;
+          ok = triHit<CLOSEST>(sc.triTest + 3 * (pr >> 1), ray, a.tMin, closest, t);
+        }
+        if (ok) {
+          closest = t;
+          hitRef = cur;
+        }
+        popNext();
+      }
+    } else {
+      // ------------------------------------------------ rayColor (main.cpp:33-52) + pixel loop (main.cpp:200-227)
+      if (mode == M_SHADE) {
+        bool needCamera = !hasRay;
+        if (hasRay) {
+          hasRay = false;
+          V3 terminal;
+          bool done;
+          if (hitRef == SRT_REF_DONE) {
+            terminal = background;  // main.cpp:39-40
             done = true;
           } else {
-            // emitted is (0,0,0) for every scattering material (material.h:18-20)
-            attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
-            attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
-            attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
-            ray = next;
-            depth++;
-            done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
-            terminal = mk(0.0f, 0.0f, 0.0f);
+            Record rec;
+            int pr = ~hitRef;
+            if (pr & 1)
+              sphereRecord(sc, pr >> 1, ray, closest, rec);
+            else
+              triRecord(sc, pr >> 1, ray, closest, rec);
+            V3 att, emitted;
+            Ray next;
+            uint32_t fetches = 0;
+            if (COUNT && rec.isTri) cShTri++;
+            bool scattered = shade<COUNT>(sc, ray, rec, rng, att, next, emitted, fetches);
+            if (COUNT) cTex += fetches;
+            if (!scattered) {
+              terminal = emitted;  // main.cpp:46-47
+              done = true;
+            } else {
+              // emitted is (0,0,0) for every scattering material (material.h:18-20)
+              attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
+              attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
+              attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
+              ray = next;
+              depth++;
+              done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
+              terminal = mk(0.0f, 0.0f, 0.0f);
+            }
+          }
+          if (done) {
+            // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
+            V3 L = terminal;
+            for (int j = depth - 1; j >= 0; --j) {
+              float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
+                    az = attStack[(3 * j + 2) * SRT_BLOCK];
+              L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
+            }
+            acc = acc + L;  // main.cpp:217
+            s++;
+            needCamera = true;
           }
         }
-        if (done) {
-          // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
-          V3 L = terminal;
-          for (int j = depth - 1; j >= 0; --j) {
-            float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
-                  az = attStack[(3 * j + 2) * SRT_BLOCK];
-            L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
+        if (needCamera && s >= sEnd) {
+          // work item finished (or none yet): write it, pull the next one with one atomic per wave
+          if (outIndex >= 0) a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
+          const unsigned long long mF = __ballot(1);
+          const int leader = __ffsll((long long)mF) - 1;
+          int base = 0;
+          if (lane == leader) base = atomicAdd(a.queue, __popcll(mF));
+          base = __shfl(base, leader);
+          const int idx = base + __popcll(mF & ((1ull << lane) - 1ull));
+          if (idx >= a.numWork) {
+            mode = M_EXIT;
+            outIndex = -1;
+          } else {
+            // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk
+            const int group = idx >> 6, ln = idx & 63;
+            const int localTile = group / a.sppChunks, chunk = group - localTile * a.sppChunks;
+            const int tile = a.tileFirst + localTile * a.tileStride;
+            const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+            px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
+            py = ty * SRT_TILE_H + (ln >> 3);
+            pixel = (uint32_t)(py * a.imageWidth + px);
+            // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
+            const int s0 = (int)(((long long)a.spp * chunk) / a.sppChunks);
+            const int s1 = (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
+            sCount = s1 - s0;
+            // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
+            const bool valid = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && a.maxBounce > 0;
+            s = s0;
+            sEnd = valid ? s1 : s0;
+            acc = mk(0.0f, 0.0f, 0.0f);
+            outIndex = (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln;
           }
-          acc = acc + L;  // main.cpp:217
-          s++;
-          needNew = true;
-          alive = s < sEnd;
+        }
+        if (mode != M_EXIT) {
+          if (needCamera && s < sEnd) {
+            rng.key(seedMixed, pixel, (uint32_t)s);
+            float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
+            float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
+            cameraRay(a.cam, u, v, rng, ray);
+            depth = 0;
+            needCamera = false;
+            if (COUNT) cSamples++;
+          }
+          if (!needCamera) {
+            // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
+            if (COUNT) cRays++;
+            rayA = lenSq(ray.d);  // sphere.h:56
+            closest = SRT_INF;
+            hitRef = SRT_REF_DONE;
+            sp = 0;
+            w = 0;
+            cur = sc.world[0];
+            mode = cur >= 0 ? M_NODE : M_PRIM;
+          }
+          // else: empty item (pixel outside the image): stays in M_SHADE and pulls again
         }
       }
     }
-    result = make_float4(acc.x, acc.y, acc.z, (float)(sEnd - (int)(((long long)a.spp * chunk) / a.sppChunks)));
-    // tile-major output: one coalesced 1 KiB store per wave
-    a.out[((size_t)chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + lane] = result;
   }
 
   if (COUNT && a.stats) {

@@ -257,6 +257,10 @@ int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, i
  * scattered origin[3], scatter's bool, emitted[3].  HOST pointers. */
 int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
 
+/* Test hook: the slab test's per-ray-reciprocal division (srt_kernels.hip fastDiv) next to the
+ * plain IEEE division on count operand pairs.  HOST pointers. */
+int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
+
 /* Duration of the most recent srtRenderTiles kernel, from HIP events recorded
  * on its stream (synchronises on the stop event). */
 int srtLastKernelMs(SrtContext* ctx, float* ms);

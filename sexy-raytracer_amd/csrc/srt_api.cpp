@@ -26,6 +26,7 @@ int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksP
 int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
 }
@@ -521,6 +522,16 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     return 1;
   s.numWorld = (int32_t)world.size();
   s.stackDepth = stackDepth;
+  s.numNodes = (int32_t)(nodes.size() / 2);
+  s.numTris = d->numTriangles;
+  s.numSpheres = d->numSpheres;
+  // fastDiv's operand certificate for the box coordinates (srt_kernels.hip): 0 or 2^-77 <= |c| <= 2^30
+  s.fastDivScene = envInt("SRT_FAST_DIV", 1);
+  for (const float4& v : nodes)
+    for (float c : {v.x, v.y, v.z}) {
+      float ac = fabsf(c);
+      if (!(c == 0.0f || (ac >= 0x1p-77f && ac <= 0x1p30f))) s.fastDivScene = 0;
+    }
   ctx->haveScene = true;
   return 0;
 }
@@ -607,7 +618,8 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.sppChunks = p->sppChunks;
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.shadeMin = envInt("SRT_SHADE_MIN", 24);
-  a.primMin = envInt("SRT_PRIM_MIN", 20);
+  a.primMin = envInt("SRT_PRIM_MIN", 12);
+  a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 4));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
@@ -743,6 +755,28 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
   if (dHits) (void)hipFree(dHits);
   if (dOut) (void)hipFree(dOut);
   return rc;
+}
+
+// test entry: the slab test's reciprocal-based division against the plain IEEE division
+int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow) {
+  if (!ctx || !n || !d || !outFast || !outSlow || count < 1) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  float* buf = nullptr;
+  size_t bytes = (size_t)count * sizeof(float);
+  HIP_OK(ctx, hipMalloc((void**)&buf, 4 * bytes));
+  int rc = 1;
+  do {
+    if (hipMemcpy(buf, n, bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemcpy(buf + count, d, bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (srt_launch_divtest(buf, buf + count, buf + 2 * (size_t)count, buf + 3 * (size_t)count, count, nullptr)) break;
+    if (hipDeviceSynchronize() != hipSuccess) break;
+    if (hipMemcpy(outFast, buf + 2 * (size_t)count, bytes, hipMemcpyDeviceToHost) != hipSuccess) break;
+    if (hipMemcpy(outSlow, buf + 3 * (size_t)count, bytes, hipMemcpyDeviceToHost) != hipSuccess) break;
+    rc = 0;
+  } while (0);
+  (void)hipFree(buf);
+  if (rc) return fail(ctx, "srtDivTest failed");
+  return 0;
 }
 
 int srtLastKernelMs(SrtContext* ctx, float* ms) {

@@ -49,6 +49,8 @@ struct DevScene {
   const int32_t* world;  // refs, world-list order
   int32_t numWorld;
   int32_t stackDepth;  // max pending right children over all trees
+  int32_t numNodes, numTris, numSpheres;  // record counts (buffer-resource extents)
+  int32_t fastDivScene;  // 1: every box coordinate is 0 or in [2^-77, 2^30] (see fastDiv in srt_kernels.hip)
   const DevMaterial* materials;
   const DevTexture* textures;
   const uint8_t* texels;  // zero padded by >= 16 bytes
@@ -71,6 +73,7 @@ struct RenderArgs {
   int32_t sppChunks;
   int32_t numWork;  // numLocalTiles * sppChunks * 64 (one item = one pixel x one sample chunk)
   int32_t shadeMin, primMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
+  int32_t nodeBurst;          // max node visits per scheduling decision
   int32_t* queue;   // persistent-wave work counter (zeroed before launch)
   float4* out;      // [chunk][localTile][64]
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr

@@ -118,6 +118,49 @@ struct Pcg {
   }
 };
 
+
+// ------------------------------------------------------------------ scene fetches
+// Raw buffer loads (SRSRC + 32-bit byte offset): one buffer_load_dwordx4 per 16-byte slot, no 64-bit
+// address arithmetic, never split or sunk by the compiler, out-of-range reads return 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t makeRsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bufLoad4(__amdgpu_buffer_rsrc_t r, int byteOffset) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byteOffset, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ------------------------------------------------------------------ exact division with a per-ray reciprocal
+// hipcc lowers the IEEE f32 division n / d to
+//   ds = div_scale(d), ns = div_scale(n); r0 = rcp(ds); r1 = fma(fma(-ds, r0, 1), r0, r0);
+//   q0 = ns*r1; q1 = fma(fma(-ds, q0, ns), r1, q0); q = div_fmas(fma(-ds, q1, ns), r1, q1); div_fixup(q, d, n)
+// When neither operand needs scaling (no zero/denormal/huge operand, quotient far from the
+// denormal and overflow ranges) div_scale, div_fmas' post-scale and div_fixup are the identity
+// and the quotient is the last fma.  r1 depends on d only, so the slab test (six divisions by the
+// three ray-direction components per BVH node, aabb.h:14-17) can reuse one r1 per axis per ray and
+// spend 5 VALU instructions per division instead of 11, with bit-identical quotients.  `rayFast`
+// certifies the operand ranges per ray (and the scene's box coordinates at upload); anything
+// outside them takes the plain `/`.  The only visible difference is the sign of a zero quotient,
+// which no comparison in the slab test can observe.
+__device__ __forceinline__ float refinedRcp(float d) {
+  float r0 = __builtin_amdgcn_rcpf(d);
+  float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float fastDiv(float n, float d, float r1) {
+  float q0 = n * r1;
+  float e1 = __builtin_fmaf(-d, q0, n);
+  float q1 = __builtin_fmaf(e1, r1, q0);
+  float e2 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(e2, r1, q1);
+}
+// direction components in [2^-20, 2^20]; origin components 0 or in [2^-77, 2^30]
+__device__ __forceinline__ bool fastDivOperandOk(float o, float d) {
+  float ad = fabsf(d), ao = fabsf(o);
+  return ad >= 0x1p-20f && ad <= 0x1p20f && (o == 0.0f || (ao >= 0x1p-77f && ao <= 0x1p30f));
+}
+
 // ------------------------------------------------------------------ rays, hits
 struct Ray {
   V3 o, d;
@@ -148,6 +191,24 @@ __device__ __forceinline__ bool boxHit(float4 n0, float4 n1, const Ray& r, float
   return !(tMax <= tMin);
 }
 
+// the same slab test with the per-ray reciprocals (see fastDiv): bit-identical decisions
+__device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax) {
+  float a, b;
+  a = fastDiv(n0.x - r.o.x, r.d.x, r1.x);
+  b = fastDiv(n1.x - r.o.x, r.d.x, r1.x);
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = fastDiv(n0.y - r.o.y, r.d.y, r1.y);
+  b = fastDiv(n1.y - r.o.y, r.d.y, r1.y);
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = fastDiv(n0.z - r.o.z, r.d.z, r1.z);
+  b = fastDiv(n1.z - r.o.z, r.d.z, r1.z);
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  return !(tMax <= tMin);
+}
+
 // sphere.h:47-52
 __device__ __forceinline__ V3 sphereCenter(const float4* sp, float4 s0, float4 s1, float time) {
   V3 c0 = mk(s0.x, s0.y, s0.z);
@@ -159,12 +220,12 @@ __device__ __forceinline__ V3 sphereCenter(const float4* sp, float4 s0, float4 s
   return c0;
 }
 
-// sphere.h:54-73: returns the root, or NaN-free miss flag
-__device__ __forceinline__ bool sphereHit(const float4* sp, const Ray& r, float a, float tMin, float tMax, float& tOut) {
-  float4 s0 = sp[0], s1 = sp[1];
-  V3 oc = r.o - sphereCenter(sp, s0, s1, r.time);
+// sphere.h:54-73 on loaded values: c = centre at the ray's time, radius
+__device__ __forceinline__ bool sphereHitV(V3 center, float radius, const Ray& r, float a, float tMin, float tMax,
+                                           float& tOut) {
+  V3 oc = r.o - center;
   float halfB = dot3(oc, r.d);
-  float c = lenSq(oc) - s0.w * s0.w;
+  float c = lenSq(oc) - radius * radius;
   float disc = halfB * halfB - a * c;
   if (disc < 0.0f) return false;
   float sqrtd = sqrtf(disc);
@@ -176,12 +237,16 @@ __device__ __forceinline__ bool sphereHit(const float4* sp, const Ray& r, float 
   tOut = root;
   return true;
 }
+__device__ __forceinline__ bool sphereHit(const float4* sp, const Ray& r, float a, float tMin, float tMax, float& tOut) {
+  float4 s0 = sp[0], s1 = sp[1];
+  return sphereHitV(sphereCenter(sp, s0, s1, r.time), s0.w, r, a, tMin, tMax, tOut);
+}
 
 // model.h:104-154.  n is precomputed on the host with the same operation order as
 // getNormal (model.h:276-283).  CLOSEST adds the t > tMax rejection the reference lacks.
 template <bool CLOSEST>
-__device__ __forceinline__ bool triHit(const float4* tr, const Ray& r, float tMin, float tMax, float& tOut) {
-  float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+__device__ __forceinline__ bool triHitV(float4 q0, float4 q1, float4 q2, const Ray& r, float tMin, float tMax,
+                                        float& tOut) {
   V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
   V3 n = mk(q0.w, q1.w, q2.w);
   float NdotDir = dot3(n, r.d);
@@ -201,6 +266,10 @@ __device__ __forceinline__ bool triHit(const float4* tr, const Ray& r, float tMi
   if (dot3(n, c) < 0) return false;
   tOut = t;
   return true;
+}
+template <bool CLOSEST>
+__device__ __forceinline__ bool triHit(const float4* tr, const Ray& r, float tMin, float tMax, float& tOut) {
+  return triHitV<CLOSEST>(tr[0], tr[1], tr[2], r, tMin, tMax, tOut);
 }
 
 // hittableList::hit over the world list (hittablelist.h:33-47) with bvhNode::hit
@@ -509,6 +578,9 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
   const DevScene& sc = a.scene;
+  const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
+  const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
+  const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
 
@@ -529,6 +601,8 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
   // traversal state (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
   int cur = SRT_REF_DONE, sp = 0, w = 0, hitRef = SRT_REF_DONE;
   float closest = SRT_INF, rayA = 0.0f;
+  V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
+  bool rayFast = false;
 
   // next pending reference after the current subtree is done; ends the traversal when none is left
   auto popNext = [&]() {
@@ -560,22 +634,32 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
 
     if (pick == M_NODE) {
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105
-      if (mode == M_NODE) {
-        float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
-        if (COUNT) cNodes++;
-        if (boxHit(n0, n1, ray, a.tMin, closest)) {
-          if (COUNT) cBox++;
-          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-          if (right != left) {
-            stack[sp * SRT_BLOCK] = right;
-            sp++;
+      // several visits per scheduling decision while most of the node lanes are still at nodes
+      const int keep = nN - (nN >> 2);
+      int budget = a.nodeBurst;
+      do {
+        if (mode == M_NODE) {
+          float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
+          if (COUNT) cNodes++;
+          bool hitBox;
+          if (rayFast)
+            hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
+          else
+            hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+          if (hitBox) {
+            if (COUNT) cBox++;
+            int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+            if (right != left) {
+              stack[sp * SRT_BLOCK] = right;
+              sp++;
+            }
+            cur = left;
+            mode = cur >= 0 ? M_NODE : M_PRIM;
+          } else {
+            popNext();
           }
-          cur = left;
-          mode = cur >= 0 ? M_NODE : M_PRIM;
-        } else {
-          popNext();
         }
-      }
+      } while (--budget > 0 && __popcll(__ballot(mode == M_NODE)) >= keep);
     } else if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
       if (mode == M_PRIM) {
@@ -584,10 +668,19 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
         bool ok;
         if (pr & 1) {
           if (COUNT) cSph++;
-          ok = sphereHit(sc.spheres + 3 * (pr >> 1), ray, rayA, a.tMin, closest, t);
+          const int off = (pr >> 1) * 48;
+          float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
+          V3 center = mk(s0.x, s0.y, s0.z);
+          if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
+            float4 s2 = bufLoad4(rsSpheres, off + 32);
+            center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
+          }
+          ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
         } else {
           if (COUNT) cTri++;
-          ok = triHit<CLOSEST>(sc.triTest + 3 * (pr >> 1), ray, a.tMin, closest, t);
+          const int off = (pr >> 1) * 48;
+          ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray,
+                                a.tMin, closest, t);
         }
         if (ok) {
           closest = t;
@@ -693,6 +786,9 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs 
             // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
             if (COUNT) cRays++;
             rayA = lenSq(ray.d);  // sphere.h:56
+            rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
+                      fastDivOperandOk(ray.o.z, ray.d.z);
+            rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
             closest = SRT_INF;
             hitRef = SRT_REF_DONE;
             sp = 0;
@@ -840,8 +936,22 @@ __global__ void srt_scatter_kernel(const ScatterArgs a) {
   o[10] = em.x; o[11] = em.y; o[12] = em.z;
 }
 
+// fastDiv vs the compiler's IEEE division on arbitrary operand arrays (srtDivTest)
+__global__ void srt_divtest_kernel(const float* n, const float* d, float* fast, float* slow, int count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float dn = d[i], nn = n[i];
+  fast[i] = fastDiv(nn, dn, refinedRcp(dn));
+  slow[i] = nn / dn;
+}
+
 // =================================================================== launch wrappers (host)
 extern "C" {
+
+int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_divtest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, n, d, fast, slow, count);
+  return (int)hipGetLastError();
+}
 
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
   dim3 g(grid), b(SRT_BLOCK);

@@ -20,7 +20,7 @@ lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
            "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles",
-           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest",
+           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest", "srtDivTest",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 
 _vp = C.c_void_p
@@ -46,6 +46,7 @@ lib.srtResolveTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _
 lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
+lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
 lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -166,6 +167,13 @@ class Context:
         out = np.zeros((len(rays), 13), np.float32)
         self._check(lib.srtScatterTest(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), seed, out.ctypes.data))
         return out
+
+    def div_test(self, n, d):
+        n = np.ascontiguousarray(n, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        fast, slow = np.zeros_like(n), np.zeros_like(n)
+        self._check(lib.srtDivTest(self.h, n.ctypes.data, d.ctypes.data, len(n), fast.ctypes.data, slow.ctypes.data))
+        return fast, slow
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

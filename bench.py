@@ -101,9 +101,10 @@ def main():
     ap.add_argument("--workload", default="masterchief_720p_5000spp", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (0 = the workload's)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--spp-chunks", type=int, default=8,
+    ap.add_argument("--spp-chunks", type=int, default=0,
                     help="work items per pixel: samples of a pixel are summed in index order inside a chunk and the "
-                         "chunk sums in chunk order (1 = the reference's single running sum, main.cpp:217)")
+                         "chunk sums in chunk order (1 = the reference's single running sum, main.cpp:217; "
+                         "0 = the library default, ~32 samples per item)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--save-png", default="")
@@ -143,7 +144,7 @@ def main():
     nloc = dev.num_local_tiles(W, H, world)
     local = torch.zeros((nloc, 64, 4), dtype=torch.float32, device="cuda")
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
-    chunks = max(1, min(args.spp_chunks, spp))
+    chunks = max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else dev.default_spp_chunks(spp)
     params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
                                        spp_chunks=chunks)
     stream = torch.cuda.current_stream().cuda_stream

@@ -178,9 +178,11 @@ typedef struct SrtRenderParams {
   int32_t traversal;   /* SRT_TRAVERSE_* */
   /* multi-GPU tile split: this call renders tiles tileFirst, tileFirst+tileStride, ... */
   int32_t tileFirst, tileStride;
-  /* samples of one pixel are summed in index order inside one chunk (the
-   * reference's order, main.cpp:204-218); chunks > 1 splits spp into that many
-   * partial sums combined in chunk order (for small images). */
+  /* One work item = one pixel x one chunk of its samples.  Samples are summed in index order
+   * inside a chunk and the chunk sums in chunk order.  1 = a single running sum per pixel, the
+   * reference's order (main.cpp:204-218), bit-reproducible against the oracle; 0 = library
+   * default srtDefaultSppChunks(spp) (fastest; differs from 1 only by the re-association of the
+   * per-pixel float sum). */
   int32_t sppChunks;
   int32_t countStats; /* 1: run the counting variant and fill srtGetStats() */
 } SrtRenderParams;
@@ -232,6 +234,8 @@ int srtGetBvhDepth(SrtContext* ctx, int32_t* depth);
  * (rank-padded) tile count of one rank: ceil(numTiles / tileStride). */
 int32_t srtNumTiles(int32_t imageWidth, int32_t imageHeight);
 int32_t srtNumLocalTiles(int32_t imageWidth, int32_t imageHeight, int32_t tileStride);
+
+int32_t srtDefaultSppChunks(int32_t spp);
 
 /* The hot path.  Asynchronous on `stream` (a hipStream_t, NULL = default).
  * dAccumTiles: DEVICE pointer, float4[numLocalTiles * 64], tile-major,

@@ -583,6 +583,15 @@ int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
   return (srtNumTiles(w, h) + stride - 1) / stride;
 }
 
+// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about
+// 32 samples per item.  Small items keep the 64 lanes of a wave on neighbouring pixels (they pull
+// consecutive items), which keeps their traversals coherent; measured on the 720p/5000-spp frame:
+// 1 chunk 563, 8 chunks 1829, 64 chunks 2023, 128-256 chunks 2082-2099, 1000 chunks 1830 Msamples/s.
+int32_t srtDefaultSppChunks(int32_t spp) {
+  int32_t c = (spp + 31) / 32;
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
 static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
   if (!ctx->haveCamera) return fail(ctx, "render: no camera set");
@@ -590,7 +599,7 @@ static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (p->spp < 1) return fail(ctx, "render: spp must be >= 1");
   if (p->maxBounce < 0 || p->maxBounce > SRT_MAX_BOUNCE) return fail(ctx, "render: maxBounce must be in [0,%d]", SRT_MAX_BOUNCE);
   if (p->tileStride < 1 || p->tileFirst < 0 || p->tileFirst >= p->tileStride) return fail(ctx, "render: bad tile split %d/%d", p->tileFirst, p->tileStride);
-  if (p->sppChunks < 1 || p->sppChunks > p->spp) return fail(ctx, "render: sppChunks must be in [1, spp]");
+  if (p->sppChunks < 0 || p->sppChunks > p->spp) return fail(ctx, "render: sppChunks must be in [0, spp] (0 = library default)");
   return 0;
 }
 
@@ -615,11 +624,11 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.tileFirst = p->tileFirst;
   a.tileStride = p->tileStride;
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
-  a.sppChunks = p->sppChunks;
+  a.sppChunks = p->sppChunks > 0 ? p->sppChunks : srtDefaultSppChunks(p->spp);
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
-  a.shadeMin = envInt("SRT_SHADE_MIN", 24);
+  a.shadeMin = envInt("SRT_SHADE_MIN", 32);
   a.primMin = envInt("SRT_PRIM_MIN", 12);
-  a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 4));
+  a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 16));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;

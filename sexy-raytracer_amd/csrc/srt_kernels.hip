@@ -33,6 +33,9 @@
 #include "srt_device.h"
 
 #define SRT_BLOCK 256
+#ifndef SRT_RENDER_WAVES_PER_SIMD
+#define SRT_RENDER_WAVES_PER_SIMD 4
+#endif
 
 namespace {
 
@@ -569,7 +572,7 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3 };
 
 template <bool CLOSEST, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK) void srt_render_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
   // per-thread LDS slots, [slot][thread]: stackDepth traversal slots, then 3*maxBounce attenuation floats
   int32_t* stack = lds + threadIdx.x;

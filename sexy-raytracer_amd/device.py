@@ -19,7 +19,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
-           "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles",
+           "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks",
            "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest", "srtDivTest",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 
@@ -41,6 +41,8 @@ lib.srtNumTiles.argtypes = [C.c_int32, C.c_int32]
 lib.srtNumTiles.restype = C.c_int32
 lib.srtNumLocalTiles.argtypes = [C.c_int32, C.c_int32, C.c_int32]
 lib.srtNumLocalTiles.restype = C.c_int32
+lib.srtDefaultSppChunks.argtypes = [C.c_int32]
+lib.srtDefaultSppChunks.restype = C.c_int32
 lib.srtRenderTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtResolveTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _vp, _vp]
 lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
@@ -78,6 +80,10 @@ def num_tiles(w, h):
 
 def num_local_tiles(w, h, stride):
     return int(lib.srtNumLocalTiles(w, h, stride))
+
+
+def default_spp_chunks(spp):
+    return int(lib.srtDefaultSppChunks(spp))
 
 
 def build_bvh_host(scene_builder, item=0, reset_rng=True):

@@ -70,13 +70,20 @@ typedef struct SrtPrimRef {
 } SrtPrimRef;
 
 /* One entry of the world list handed to rayColor (main.cpp:146,187):
- * a bare primitive, or a bvhNode built over prims[first, first+count)
- * with the (time0,time1) given to its ctor (bvh.h:15-16). */
+ * a bare primitive, or a bvhNode over prims[first, first+count) with the
+ * (time0,time1) given to its ctor (bvh.h:15-16).  nodes == NULL: the library
+ * builds the tree (bvh.h:55-95, consuming the global generator); otherwise the
+ * caller supplies an already built tree (e.g. from srtBuildBvh at bvhNode
+ * construction time, or its own builder): numNodes records in pre-order, node 0
+ * the root, child >= 0 a node index GREATER than its parent's, child < 0 a
+ * primitive ~child inside [first, first+count). */
 typedef struct SrtWorldItem {
   int32_t kind; /* SRT_WORLD_* */
   int32_t first;
   int32_t count;
   float time0, time1;
+  int32_t numNodes;
+  const struct SrtBvhNode* nodes;
 } SrtWorldItem;
 
 /* material.h.  Field use per type:

@@ -32,7 +32,8 @@ class SrtPrimRef(C.Structure):
 
 
 class SrtWorldItem(C.Structure):
-    _fields_ = [("kind", i32), ("first", i32), ("count", i32), ("time0", f32), ("time1", f32)]
+    _fields_ = [("kind", i32), ("first", i32), ("count", i32), ("time0", f32), ("time1", f32),
+                ("numNodes", i32), ("nodes", C.c_void_p)]
 
 
 class SrtMaterialIn(C.Structure):
@@ -230,10 +231,18 @@ class SceneBuilder:
     def world_bvh(self, first=0, count=None, time0=0.0, time1=1.0):
         if count is None:
             count = self.num_prims - first
-        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1))
+        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, 0, None))
+
+    def world_prebuilt(self, nodes, first=0, count=None, time0=0.0, time1=1.0):
+        """A caller-built tree (NODE_DTYPE array, pre-order, child refs as in SrtBvhNode)."""
+        if count is None:
+            count = self.num_prims - first
+        nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+        self._prebuilt = getattr(self, "_prebuilt", []) + [nodes]
+        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, len(nodes), nodes.ctypes.data))
 
     def world_prim(self, prim):
-        self.world.append(SrtWorldItem(SRT_WORLD_PRIM, prim, 1, 0.0, 0.0))
+        self.world.append(SrtWorldItem(SRT_WORLD_PRIM, prim, 1, 0.0, 0.0, 0, None))
 
     def desc(self):
         def arr(ctype, items):

@@ -167,11 +167,28 @@ struct Builder {
   }
 };
 
-// make_shared<bvhNode>(objects, time0, time1) over one world item (main.cpp:146, bvh.h:15-16)
+// make_shared<bvhNode>(objects, time0, time1) over one world item (main.cpp:146, bvh.h:15-16),
+// or adoption of a caller-built tree (validated by validateScene).
 void buildItem(const SrtSceneDesc* d, const SrtWorldItem& it, Builder& b) {
   b.d = d;
   b.time0 = it.time0;
   b.time1 = it.time1;
+  if (it.nodes) {
+    b.nodes.resize(it.numNodes);
+    std::vector<int> pending(it.numNodes, 0);  // stack entries held when the node is entered
+    for (int i = 0; i < it.numNodes; ++i) {
+      const SrtBvhNode& n = it.nodes[i];
+      memcpy(b.nodes[i].box.mn, n.bmin, 12);
+      memcpy(b.nodes[i].box.mx, n.bmax, 12);
+      b.nodes[i].left = n.left;
+      b.nodes[i].right = n.right;
+      const bool two = n.right != n.left;
+      if (two) b.maxPending = std::max(b.maxPending, pending[i] + 1);
+      if (n.left >= 0) pending[n.left] = pending[i] + (two ? 1 : 0);
+      if (two && n.right >= 0) pending[n.right] = pending[i];
+    }
+    return;
+  }
   b.sortKey.resize((size_t)d->numPrims * 3);
   b.objects.resize(it.count);
   for (int i = 0; i < it.count; ++i) {
@@ -303,6 +320,15 @@ int validateScene(SrtContext* ctx, const SrtSceneDesc* d) {
     const SrtWorldItem& it = d->world[w];
     if (it.first < 0 || it.count < 1 || it.first + it.count > d->numPrims || (it.kind != SRT_WORLD_PRIM && it.kind != SRT_WORLD_BVH))
       return fail(ctx, "world item %d: bad range", w);
+    if (it.kind == SRT_WORLD_BVH && it.nodes) {
+      // a caller-built tree must be finite and acyclic: children point forward (pre-order)
+      if (it.numNodes < 1) return fail(ctx, "world item %d: prebuilt tree without nodes", w);
+      for (int i = 0; i < it.numNodes; ++i)
+        for (int32_t c : {it.nodes[i].left, it.nodes[i].right}) {
+          if (c >= 0 ? (c <= i || c >= it.numNodes) : (~c < it.first || ~c >= it.first + it.count))
+            return fail(ctx, "world item %d: prebuilt node %d has a bad child reference %d", w, i, c);
+        }
+    }
   }
 
   return 0;

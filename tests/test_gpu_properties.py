@@ -194,7 +194,7 @@ def test_error_behaviour(dev, abi, srt, camera):
     with pytest.raises(dev.SrtError, match="no camera"):
         c.render_image(p)
     c.set_camera(camera)
-    for field, bad in (("spp", 0), ("maxBounce", 99), ("imageWidth", 1), ("sppChunks", 0)):
+    for field, bad in (("spp", 0), ("maxBounce", 99), ("imageWidth", 1), ("sppChunks", -1), ("sppChunks", 2)):
         q = abi.default_render_params(64, 36, 1, 4)
         setattr(q, field, bad)
         with pytest.raises(dev.SrtError):

@@ -1,0 +1,104 @@
+"""The C++ host layer (sexy-raytracer_amd/host/srt/*.h: the reference's class names over the C-ABI)
+against the Python scene path and the oracle, on CPU: glTF loader (gltfLoad semantics), PNG decoder
+and writer, flattening, bvhNode built at construction from the process-global generator."""
+import hashlib
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+TRI = np.dtype([("p", "<f4", (3, 3)), ("uv", "<f4", (3, 2)), ("material", "<i4")])
+SPH = np.dtype([("c0", "<f4", 3), ("c1", "<f4", 3), ("t0", "<f4"), ("t1", "<f4"), ("r", "<f4"), ("material", "<i4")])
+TEX = np.dtype([("kind", "<i4"), ("w", "<i4"), ("h", "<i4"), ("bpp", "<i4"), ("off", "<i8"), ("even", "<i4"),
+                ("odd", "<i4"), ("color", "<f4", 3), ("pad", "<i4")])
+
+
+def _read(f, dtype):
+    n = struct.unpack("<q", f.read(8))[0]
+    return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype)
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory, dev):
+    exe = os.path.join(ROOT, "examples", "srt_flatten_dump")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sexy-raytracer_amd", "host")])
+    d = tmp_path_factory.mktemp("flat")
+    out, png = str(d / "flat.bin"), str(d / "roundtrip.png")
+    env = dict(os.environ, SRT_DATA_DIR=os.path.join(ROOT, "assets"))
+    subprocess.check_call([exe, os.path.join(ROOT, "assets", "masterchief2-separate-xf.gltf"), out, png], env=env)
+    with open(out, "rb") as f:
+        r = {"tri": _read(f, TRI), "sph": _read(f, SPH), "prims": _read(f, np.dtype(("<i4", 2))).reshape(-1, 2),
+             "mat": _read(f, np.dtype(("<i4", 16))), "tex": _read(f, TEX), "texels": _read(f, "u1")}
+        from importlib import import_module
+        r["nodes"] = _read(f, import_module("sexy-raytracer_amd.abi").NODE_DTYPE)
+        r["next"] = _read(f, "<f4")
+    r["png"] = png
+    return r
+
+
+def _python_scene(srt):
+    sb = srt.abi.SceneBuilder()
+    srt.scenes.add_masterchief(sb)
+    chk = sb.checker((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))
+    sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=chk))
+    sb.add_sphere((3.0, 1.0, 0.0), 1.0, sb.metal((0.7, 0.6, 0.5), 0.0))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+def test_cpp_gltf_and_flatten_match_python(dump, srt):
+    sb = _python_scene(srt)
+    tri = np.concatenate(sb.triangles)
+    assert len(dump["tri"]) == 3042 and dump["tri"]["p"].tobytes() == tri["p"].tobytes()
+    assert dump["tri"]["uv"].tobytes() == tri["uv"].tobytes()
+    assert np.array_equal(dump["prims"], np.concatenate(sb._prim_chunks))
+    assert np.allclose(dump["sph"]["c0"], [[0, -1000, 0], [3, 1, 0]]) and dump["sph"]["r"].tolist() == [1000.0, 1.0]
+
+
+def test_cpp_png_decoder_matches_pil(dump):
+    from PIL import Image
+    want = {}
+    for name in ("Image_0.png", "Image_1.png"):
+        a = np.asarray(Image.open(os.path.join(ROOT, "assets", name)).convert("RGB"), dtype=np.uint8)
+        want[hashlib.sha1(a.tobytes()).hexdigest()] = a.shape
+    seen = set()
+    for t in dump["tex"]:
+        if t["kind"] == 2 and t["w"] > 0:
+            b = dump["texels"][t["off"]:t["off"] + int(t["w"]) * t["h"] * t["bpp"]]
+            h = hashlib.sha1(b.tobytes()).hexdigest()
+            assert h in want and want[h] == (t["h"], t["w"], t["bpp"])
+            seen.add(h)
+    assert seen == set(want)
+    # the writer's output is a valid PNG that PIL decodes to the same bytes
+    back = np.asarray(Image.open(dump["png"]).convert("RGB"), dtype=np.uint8)
+    assert hashlib.sha1(back.tobytes()).hexdigest() in want
+
+
+def test_cpp_bvhnode_is_the_reference_build(dump, srt, oracle):
+    """bvhNode built at construction through srtBuildBvh == the oracle's bvh.h:55-95 restatement, and
+    the process-global generator has advanced by exactly one draw per node (globals.h:30-35)."""
+    sb = _python_scene(srt)
+    onodes, _ = oracle.OracleScene(sb).bvh(0)
+    assert dump["nodes"].tobytes() == onodes.tobytes()
+    n = len(onodes)
+    assert dump["next"][0] == oracle.rng_kat(n + 1)[n]
+
+
+def test_cpp_material_flattening(dump):
+    mats = dump["mat"].view(np.dtype([("type", "<i4"), ("tex", "<i4", 4), ("albedo", "<f4", 4), ("metalness", "<f4"),
+                                       ("roughness", "<f4"), ("fuzz", "<f4"), ("ir", "<f4"), ("pad", "<i4", 3)]))
+    mats = mats.reshape(-1)
+    # two mesh materials (pbr: albedo+normal maps, metallic 0, roughness 1 = glTF default), ground pbr, metal
+    assert mats["type"].tolist() == [0, 0, 0, 1]
+    assert (mats["tex"][:2, :2] >= 0).all() and (mats["tex"][:2, 2:] == -1).all()
+    assert mats["metalness"][:2].tolist() == [0.0, 0.0] and mats["roughness"][:2].tolist() == [1.0, 1.0]
+    assert mats["metalness"][2] == 0.0 and mats["roughness"][2] == 0.0  # ctor material.h:29-32, defined as 0
+    assert np.allclose(mats["albedo"][3][:3], [0.7, 0.6, 0.5]) and mats["fuzz"][3] == 0.0
+    ground_tex = dump["tex"][mats["tex"][2][0]]
+    assert ground_tex["kind"] == 1  # checker
+    assert np.allclose(dump["tex"][ground_tex["even"]]["color"], [0.2, 0.3, 0.1])
+    assert np.allclose(dump["tex"][ground_tex["odd"]]["color"], [0.9, 0.9, 0.9])

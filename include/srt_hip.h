@@ -199,6 +199,11 @@ typedef struct SrtStats {
   uint64_t samples, rays;
   uint64_t nodeVisits, boxPasses, triTests, sphereTests;
   uint64_t shadedTriHits, texelFetches;
+  /* wave-scheduler profile of the counting variant (diagnostics, not part of any parity claim):
+   * shader clocks spent in, executions of, and lanes active in each step kind, summed over waves */
+  uint64_t cyclesNode, cyclesPrim, cyclesShade, cyclesTotal;
+  uint64_t stepsNode, stepsPrim, stepsShade;
+  uint64_t lanesNode, lanesPrim, lanesShade;
 } SrtStats;
 
 typedef struct SrtContext SrtContext;

@@ -90,7 +90,10 @@ class SrtRenderParams(C.Structure):
 
 class SrtStats(C.Structure):
     _fields_ = [("samples", u64), ("rays", u64), ("nodeVisits", u64), ("boxPasses", u64),
-                ("triTests", u64), ("sphereTests", u64), ("shadedTriHits", u64), ("texelFetches", u64)]
+                ("triTests", u64), ("sphereTests", u64), ("shadedTriHits", u64), ("texelFetches", u64),
+                ("cyclesNode", u64), ("cyclesPrim", u64), ("cyclesShade", u64), ("cyclesTotal", u64),
+                ("stepsNode", u64), ("stepsPrim", u64), ("stepsShade", u64),
+                ("lanesNode", u64), ("lanesPrim", u64), ("lanesShade", u64)]
 
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("time", "<f4"), ("tMin", "<f4"), ("tMax", "<f4")])

@@ -349,7 +349,7 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   HIP_OK(ctx, hipSetDevice(deviceOrdinal));
   HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
   HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, 64));
-  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 8 * sizeof(unsigned long long)));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 18 * sizeof(unsigned long long)));
   HIP_OK(ctx, hipEventCreate(&ctx->evStart));
   HIP_OK(ctx, hipEventCreate(&ctx->evStop));
   *out = ctx;
@@ -527,6 +527,17 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     o.metalness = m.type == SRT_MAT_METAL ? (m.fuzz < 1.0f ? m.fuzz : 1.0f)  // material.h:89
                   : m.type == SRT_MAT_DIELECTRIC ? m.ir : m.metalness;
     o.roughness = m.roughness;
+    // which hitRecord fields this material can observe (srt_kernels.hip sphereRecord/triRecord)
+    auto readsUv = [&](int tex) {
+      if (tex < 0) return false;
+      const SrtTextureIn& t = d->textures[tex];
+      if (t.kind == SRT_TEX_IMAGE) return true;
+      if (t.kind == SRT_TEX_CHECKER) return d->textures[t.even].kind == SRT_TEX_IMAGE || d->textures[t.odd].kind == SRT_TEX_IMAGE;
+      return false;
+    };
+    bool uv = readsUv(m.albedoTex);
+    if (m.type == SRT_MAT_PBR) uv = uv || readsUv(m.normalTex) || readsUv(m.metallicTex) || readsUv(m.roughnessTex);
+    o.flags = (uv ? 1 : 0) | ((m.type == SRT_MAT_PBR && m.normalTex >= 0) ? 2 : 0);
   }
   std::vector<DevTexture> texs(d->numTextures);
   for (int i = 0; i < d->numTextures; ++i) {
@@ -678,7 +689,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t), stream));
-  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 8 * sizeof(unsigned long long), stream));
+  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 18 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
   int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -826,10 +837,13 @@ int srtGetStats(SrtContext* ctx, SrtStats* out) {
   if (!ctx || !out) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   HIP_OK(ctx, hipDeviceSynchronize());
-  unsigned long long v[8];
+  unsigned long long v[18];
   HIP_OK(ctx, hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost));
   out->samples = v[0]; out->rays = v[1]; out->nodeVisits = v[2]; out->boxPasses = v[3];
   out->triTests = v[4]; out->sphereTests = v[5]; out->shadedTriHits = v[6]; out->texelFetches = v[7];
+  out->cyclesNode = v[8]; out->cyclesPrim = v[9]; out->cyclesShade = v[10]; out->cyclesTotal = v[11];
+  out->stepsNode = v[12]; out->stepsPrim = v[13]; out->stepsShade = v[14];
+  out->lanesNode = v[15]; out->lanesPrim = v[16]; out->lanesShade = v[17];
   return 0;
 }
 

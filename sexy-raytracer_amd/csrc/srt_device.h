@@ -22,7 +22,7 @@ struct DevMaterial {  // 48 B
   int32_t albedoTex, normalTex, metallicTex, roughnessTex;
   float albedo[4];
   float metalness, roughness;  // METAL: metalness = fuzz; DIELECTRIC: metalness = ir
-  int32_t pad;
+  int32_t flags;               // bit0: some texture of this material reads uv; bit1: it has a normal map
 };
 
 struct DevTexture {  // 48 B

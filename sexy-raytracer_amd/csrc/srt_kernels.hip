@@ -349,46 +349,63 @@ __device__ __forceinline__ void setFaceNormal(Record& rec, const Ray& r, V3 outw
   rec.normal = rec.frontFace ? outward : -outward;
 }
 
-__device__ __forceinline__ void sphereRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec) {
+// The reference fills every field of hitRecord on every hit (sphere.h:74-80, model.h:156-178).
+// uv is only ever read by image-texture lookups and the tangent frame only by normal mapping, so
+// the render kernel computes them when the hit material can use them (DevMaterial::flags, set at
+// upload); `all` forces everything (fixed-ray-set output).
+#define SRT_MAT_NEEDS_UV 1
+#define SRT_MAT_NEEDS_TANGENT 2
+
+__device__ __forceinline__ void sphereRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec, bool all) {
   const float4* sp = sc.spheres + 3 * idx;
   float4 s0 = sp[0], s1 = sp[1];
   rec.t = t;
   rec.p = r.o + t * r.d;                                                  // ray.h:15-17
   V3 outward = unitv(rec.p - sphereCenter(sp, s0, s1, r.time));           // sphere.h:76
   setFaceNormal(rec, r, outward);
-  float theta = acosf(-outward.y);                                        // sphere.h:32-38
-  float phi = atan2f(-outward.z, outward.x) + SRT_PI;
-  rec.u = phi / (2.0f * SRT_PI);
-  rec.v = theta / SRT_PI;
   rec.material = __float_as_int(s1.w) & 0x3fffffff;
   rec.isTri = false;
-  // sphere.h:96-106; dot(n, UnitY) = n.x*0 + (n.y*1 + n.z*0)
-  float ny = outward.x * 0.0f + (outward.y * 1.0f + outward.z * 0.0f);
-  V3 b = (1.0f - fabsf(ny) < SRT_EPS) ? mk(-0.0f, -0.0f, -1.0f) : mk(0.0f, 1.0f, 0.0f);
-  rec.tangent = unitv(cross3(b, outward));
-  rec.bitangent = unitv(cross3(outward, rec.tangent));
+  const int flags = all ? 3 : sc.materials[rec.material].flags;
+  rec.u = rec.v = 0.0f;
+  if (flags & SRT_MAT_NEEDS_UV) {
+    float theta = acosf(-outward.y);                                      // sphere.h:32-38
+    float phi = atan2f(-outward.z, outward.x) + SRT_PI;
+    rec.u = phi / (2.0f * SRT_PI);
+    rec.v = theta / SRT_PI;
+  }
+  rec.tangent = rec.bitangent = mk(0.0f, 0.0f, 0.0f);
+  if (flags & SRT_MAT_NEEDS_TANGENT) {
+    // sphere.h:96-106; dot(n, UnitY) = n.x*0 + (n.y*1 + n.z*0)
+    float ny = outward.x * 0.0f + (outward.y * 1.0f + outward.z * 0.0f);
+    V3 b = (1.0f - fabsf(ny) < SRT_EPS) ? mk(-0.0f, -0.0f, -1.0f) : mk(0.0f, 1.0f, 0.0f);
+    rec.tangent = unitv(cross3(b, outward));
+    rec.bitangent = unitv(cross3(outward, rec.tangent));
+  }
 }
 
-__device__ __forceinline__ void triRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec) {
+__device__ __forceinline__ void triRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec, bool all) {
   const float4* tr = sc.triTest + 3 * idx;
   const float4* sh = sc.triShade + 4 * idx;
-  float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
   float4 h0 = sh[0], h1 = sh[1], h2 = sh[2], h3 = sh[3];
-  V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
   V3 p = r.o + t * r.d;
-  // inverse-distance weights (model.h:158-169)
-  float d0 = dist3(p, v0), d1 = dist3(p, v1), d2 = dist3(p, v2);
-  float denom = (1.0f / d0) + (1.0f / d1) + (1.0f / d2);
-  float r0 = (1.0f / d0) / denom, r1 = (1.0f / d1) / denom, r2 = (1.0f / d2) / denom;
-  rec.u = r0 * h0.w + r1 * h2.w + r2 * h3.y;
-  rec.v = 1.0f - (r0 * h1.w + r1 * h3.x + r2 * h3.z);
+  rec.material = __float_as_int(h3.w);
+  rec.isTri = true;
+  rec.u = rec.v = 0.0f;
+  if (all || (sc.materials[rec.material].flags & SRT_MAT_NEEDS_UV)) {
+    float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+    V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
+    // inverse-distance weights (model.h:158-169)
+    float d0 = dist3(p, v0), d1 = dist3(p, v1), d2 = dist3(p, v2);
+    float denom = (1.0f / d0) + (1.0f / d1) + (1.0f / d2);
+    float r0 = (1.0f / d0) / denom, r1 = (1.0f / d1) / denom, r2 = (1.0f / d2) / denom;
+    rec.u = r0 * h0.w + r1 * h2.w + r2 * h3.y;
+    rec.v = 1.0f - (r0 * h1.w + r1 * h3.x + r2 * h3.z);
+  }
   rec.t = t;
   rec.p = p;
   setFaceNormal(rec, r, mk(h0.x, h0.y, h0.z));  // unitVector(normal) precomputed (model.h:172)
   rec.tangent = mk(h1.x, h1.y, h1.z);          // calcTangentBasis precomputed (model.h:214-235)
   rec.bitangent = mk(h2.x, h2.y, h2.z);
-  rec.material = __float_as_int(h3.w);
-  rec.isTri = true;
 }
 
 // ------------------------------------------------------------------ textures (texture.h)
@@ -586,6 +603,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
+  // scheduler profile (COUNT variant only; wave-uniform)
+  unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
+  const unsigned long long pStart = COUNT ? clock64() : 0;
 
   // ---- lane state
   int mode = M_SHADE;
@@ -634,6 +654,11 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     else
       pick = M_NODE;
     pick = __builtin_amdgcn_readfirstlane(pick);
+    const unsigned long long pT0 = COUNT ? clock64() : 0;
+    if (COUNT && pick != M_NODE) {
+      pSteps[pick]++;
+      pLanes[pick] += pick == M_PRIM ? nP : nS;
+    }
 
     if (pick == M_NODE) {
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105
@@ -641,6 +666,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       const int keep = nN - (nN >> 2);
       int budget = a.nodeBurst;
       do {
+        if (COUNT) {
+          pSteps[M_NODE]++;
+          pLanes[M_NODE] += __popcll(__ballot(mode == M_NODE));
+        }
         if (mode == M_NODE) {
           float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
           if (COUNT) cNodes++;
@@ -706,9 +735,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             Record rec;
             int pr = ~hitRef;
             if (pr & 1)
-              sphereRecord(sc, pr >> 1, ray, closest, rec);
+              sphereRecord(sc, pr >> 1, ray, closest, rec, false);
             else
-              triRecord(sc, pr >> 1, ray, closest, rec);
+              triRecord(sc, pr >> 1, ray, closest, rec, false);
             V3 att, emitted;
             Ray next;
             uint32_t fetches = 0;
@@ -803,6 +832,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         }
       }
     }
+    if (COUNT) pCyc[pick] += clock64() - pT0;
   }
 
   if (COUNT && a.stats) {
@@ -811,6 +841,14 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       unsigned long long x = v[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
       if (lane == 0) atomicAdd(&a.stats[k], x);
+    }
+    if (lane == 0) {
+      for (int k = 0; k < 3; ++k) {
+        atomicAdd(&a.stats[8 + k], pCyc[k]);
+        atomicAdd(&a.stats[12 + k], pSteps[k]);
+        atomicAdd(&a.stats[15 + k], pLanes[k]);
+      }
+      atomicAdd(&a.stats[11], (unsigned long long)(clock64() - pStart));
     }
   }
 }
@@ -879,10 +917,10 @@ __global__ __launch_bounds__(SRT_BLOCK) void srt_trace_kernel(const TraceArgs a)
       Record rec;
       int pr = ~ref;
       if (pr & 1) {
-        sphereRecord(a.scene, pr >> 1, r, tHit, rec);
+        sphereRecord(a.scene, pr >> 1, r, tHit, rec, true);
         h.prim = a.scene.sphPrimId[pr >> 1];
       } else {
-        triRecord(a.scene, pr >> 1, r, tHit, rec);
+        triRecord(a.scene, pr >> 1, r, tHit, rec, true);
         h.prim = a.scene.triPrimId[pr >> 1];
       }
       h.t = rec.t;

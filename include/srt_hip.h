@@ -192,6 +192,10 @@ typedef struct SrtRenderParams {
    * per-pixel float sum). */
   int32_t sppChunks;
   int32_t countStats; /* 1: run the counting variant and fill srtGetStats() */
+  /* progressive rendering: this call renders samples [sampleFirst, sampleFirst + spp) of every
+   * pixel (RNG keys use the absolute sample index), so passes can be added up, checkpointed and
+   * resumed; the reference only writes once at the very end (main.cpp:235-237). */
+  int32_t sampleFirst;
 } SrtRenderParams;
 
 /* counters behind the algorithmic-bytes figure */

@@ -953,7 +953,7 @@ int orc_render(void* h, const SrtCamera* cam, const SrtRenderParams* p, int rngM
     for (int y = rowBegin; y < rowEnd; ++y) {
       for (int x = 0; x < W; ++x) {
         vec3 pixelColor(0, 0, 0);
-        for (int sIdx = 0; sIdx < p->spp; ++sIdx) {
+        for (int sIdx = p->sampleFirst; sIdx < p->sampleFirst + p->spp; ++sIdx) {
           if (rngMode == RNG_COUNTER) rng.key(p->seed, (uint32_t)(y * W + x), (uint32_t)sIdx);
           COUNT(samples);
           float u = (float)(x + rng.randomFloat()) / (W - 1);           // main.cpp:210

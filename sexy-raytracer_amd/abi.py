@@ -85,7 +85,8 @@ class SrtHit(C.Structure):
 class SrtRenderParams(C.Structure):
     _fields_ = [("imageWidth", i32), ("imageHeight", i32), ("spp", i32), ("maxBounce", i32),
                 ("seed", u64), ("background", f32 * 3), ("tMin", f32), ("traversal", i32),
-                ("tileFirst", i32), ("tileStride", i32), ("sppChunks", i32), ("countStats", i32)]
+                ("tileFirst", i32), ("tileStride", i32), ("sppChunks", i32), ("countStats", i32),
+                ("sampleFirst", i32)]
 
 
 class SrtStats(C.Structure):
@@ -110,7 +111,7 @@ assert C.sizeof(SrtTriangleIn) == 64
 
 def default_render_params(width, height, spp, max_bounce, seed=1, background=(0.53, 0.81, 0.92),
                           traversal=SRT_TRAVERSE_FAITHFUL, tile_first=0, tile_stride=1, spp_chunks=1,
-                          count_stats=0):
+                          count_stats=0, sample_first=0):
     """main.cpp:170-180 defaults (background sky blue, tMin 0.001)."""
     p = SrtRenderParams()
     p.imageWidth, p.imageHeight, p.spp, p.maxBounce = width, height, spp, max_bounce
@@ -119,6 +120,7 @@ def default_render_params(width, height, spp, max_bounce, seed=1, background=(0.
     p.tMin = 0.001
     p.traversal = traversal
     p.tileFirst, p.tileStride, p.sppChunks, p.countStats = tile_first, tile_stride, spp_chunks, count_stats
+    p.sampleFirst = sample_first
     return p
 
 

@@ -634,6 +634,7 @@ static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveCamera) return fail(ctx, "render: no camera set");
   if (p->imageWidth < 2 || p->imageHeight < 2) return fail(ctx, "render: image must be at least 2x2 (u,v divide by W-1,H-1)");
   if (p->spp < 1) return fail(ctx, "render: spp must be >= 1");
+  if (p->sampleFirst < 0 || (int64_t)p->sampleFirst + p->spp > 0x7fffffff) return fail(ctx, "render: bad sample range");
   if (p->maxBounce < 0 || p->maxBounce > SRT_MAX_BOUNCE) return fail(ctx, "render: maxBounce must be in [0,%d]", SRT_MAX_BOUNCE);
   if (p->tileStride < 1 || p->tileFirst < 0 || p->tileFirst >= p->tileStride) return fail(ctx, "render: bad tile split %d/%d", p->tileFirst, p->tileStride);
   if (p->sppChunks < 0 || p->sppChunks > p->spp) return fail(ctx, "render: sppChunks must be in [0, spp] (0 = library default)");
@@ -655,6 +656,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.numTiles = srtNumTiles(p->imageWidth, p->imageHeight);
   a.spp = p->spp;
   a.maxBounce = p->maxBounce;
+  a.sampleFirst = p->sampleFirst;
   a.seed = p->seed;
   memcpy(a.background, p->background, 12);
   a.tMin = p->tMin;

@@ -65,7 +65,7 @@ struct RenderArgs {
   DevScene scene;
   DevCamera cam;
   int32_t imageWidth, imageHeight, tilesX, numTiles;
-  int32_t spp, maxBounce;
+  int32_t spp, maxBounce, sampleFirst;
   uint64_t seed;
   float background[3];
   float tMin;

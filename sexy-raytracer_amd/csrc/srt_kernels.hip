@@ -793,8 +793,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             py = ty * SRT_TILE_H + (ln >> 3);
             pixel = (uint32_t)(py * a.imageWidth + px);
             // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
-            const int s0 = (int)(((long long)a.spp * chunk) / a.sppChunks);
-            const int s1 = (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
+            const int s0 = a.sampleFirst + (int)(((long long)a.spp * chunk) / a.sppChunks);
+            const int s1 = a.sampleFirst + (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
             sCount = s1 - s0;
             // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
             const bool valid = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && a.maxBounce > 0;

@@ -236,3 +236,22 @@ def test_fast_division_is_the_ieee_division(ctx):
     assert (fast[~nz] == 0).all()  # only the sign of a zero quotient may differ
     want = (n.astype(np.float64) / d.astype(np.float64)).astype(np.float32)
     assert np.array_equal(slow.view(np.uint32), want.view(np.uint32))
+
+
+def test_progressive_passes_checkpoint_and_resume(tmp_path, ctx, abi, srt, camera):
+    """Two passes of 8 samples (with a checkpoint written and resumed in between) add up bit for bit
+    to one 16-sample render whose per-pixel sum is taken as two 8-sample chunks."""
+    import importlib
+    prog = importlib.import_module("sexy-raytracer_amd.progressive")
+    ctx.upload_scene(srt.scenes.scene_masterchief())
+    ctx.set_camera(camera)
+    pr = prog.ProgressiveRender(ctx, abi, 160, 90, 4, seed=21)
+    pr.render_pass(8)
+    ck = str(tmp_path / "ck.npz")
+    pr.save(ck)
+    pr2 = prog.ProgressiveRender.resume(ctx, abi, ck)
+    assert pr2.next_sample == 8
+    pr2.render_pass(8)
+    want, want_rgba = ctx.render_image(abi.default_render_params(160, 90, 16, 4, seed=21, spp_chunks=2))
+    assert pr2.accum.tobytes() == want.tobytes()
+    assert np.array_equal(pr2.image_rgba8(), want_rgba)

@@ -44,6 +44,10 @@ def gather_tiles(local, rank, world):
     import torch.distributed as dist
     if world == 1:
         return local.unsqueeze(0)
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # rehearsal only (several ranks sharing one GPU, SRT_BENCH_BACKEND=gloo): gloo gathers host tensors
+        host = gather_tiles(local.cpu(), rank, world)
+        return host.to(local.device) if rank == 0 else None
     if rank == 0:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.gather(local, [out[i] for i in range(world)], dst=0)
@@ -123,11 +127,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the hot path)")
+    backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only to rehearse N ranks on one GPU
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     srt = importlib.import_module("sexy-raytracer_amd")
     abi, dev = srt.abi, srt.device()
@@ -173,10 +183,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device="cuda")
+        k = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         avg_kernel_ms = float(k.item())
     else:
@@ -192,7 +203,7 @@ def main():
     st = ctx.stats()
     if world > 1:
         keys = sorted(st)
-        v = torch.tensor([st[k] for k in keys], dtype=torch.int64, device="cuda")
+        v = torch.tensor([st[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(v)
         st = dict(zip(keys, [int(x) for x in v.tolist()]))
     if rank == 0:

@@ -212,6 +212,33 @@ __device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V
   return !(tMax <= tMin);
 }
 
+// Slab test decided from one-multiply quotients with an error certificate.
+// q' = n * r1 is within 1.8e-7 (relative) of the correctly rounded n / d the reference computes
+// (r1 within 1 ulp of 1/d, one rounding in the product; operands certified normal by rayFast).
+// min/max preserve a relative bound: |max_i x_i - max_i x'_i| <= eps*|max_i x'_i| when every
+// |x_i - x'_i| <= eps*|x'_i| (tMin and the running closest t are exact), so the approximate interval
+// ends tMinA, tMaxA are within eps of the exact ones and the reference's decision (tMax <= tMin ->
+// miss) is certain whenever |tMaxA - tMinA| > eps*(|tMaxA| + |tMinA|), eps = 2^-21 (2.6x the bound).
+// Returns +1 certain hit, -1 certain miss, 0 undecided (the caller then runs the exact test).
+__device__ __forceinline__ int boxHitApprox(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax) {
+  float a, b;
+  a = (n0.x - r.o.x) * r1.x;
+  b = (n1.x - r.o.x) * r1.x;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = (n0.y - r.o.y) * r1.y;
+  b = (n1.y - r.o.y) * r1.y;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  a = (n0.z - r.o.z) * r1.z;
+  b = (n1.z - r.o.z) * r1.z;
+  tMin = fmaxf(fminf(a, b), tMin);
+  tMax = fminf(fmaxf(a, b), tMax);
+  const float diff = tMax - tMin;
+  const float tol = 0x1p-21f * (fabsf(tMax) + fabsf(tMin));
+  return diff > tol ? 1 : (-diff > tol ? -1 : 0);
+}
+
 // sphere.h:47-52
 __device__ __forceinline__ V3 sphereCenter(const float4* sp, float4 s0, float4 s1, float time) {
   V3 c0 = mk(s0.x, s0.y, s0.z);
@@ -674,10 +701,13 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
           if (COUNT) cNodes++;
           bool hitBox;
-          if (rayFast)
-            hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
-          else
+          if (rayFast) {
+            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
+            hitBox = sure > 0;
+            if (sure == 0) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);  // rare: exact quotients
+          } else {
             hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+          }
           if (hitBox) {
             if (COUNT) cBox++;
             int left = __float_as_int(n0.w), right = __float_as_int(n1.w);

@@ -1,17 +1,27 @@
+// Axis-aligned box of the host scene description (role of the reference's aabb.h:6-43).
+// Only the data and the union are needed on the host; the slab test is device code
+// (srt_kernels.hip boxHit / boxHitApprox).
 #ifndef SRT_HOST_AABB_H
 #define SRT_HOST_AABB_H
+
 #include <cmath>
+
 #include "vec3.h"
-// aabb.h:6-43 (the slab test aabb::hit is device code: srt_kernels.hip boxHit)
-class aabb {
- public:
-  aabb() {}
-  aabb(const vec3f& a, const vec3f& b) : minimum(a), maximum(b) {}
+
+struct aabb {
   vec3f minimum, maximum;
+  aabb() = default;
+  aabb(const vec3f& lo, const vec3f& hi) : minimum(lo), maximum(hi) {}
 };
-inline aabb surroundingBox(aabb box0, aabb box1) {
-  vec3f small(fminf(box0.minimum(0), box1.minimum(0)), fminf(box0.minimum(1), box1.minimum(1)), fminf(box0.minimum(2), box1.minimum(2)));
-  vec3f large(fmaxf(box0.maximum(0), box1.maximum(0)), fmaxf(box0.maximum(1), box1.maximum(1)), fmaxf(box0.maximum(2), box1.maximum(2)));
-  return aabb(small, large);
+
+// union of two boxes, component by component with fminf / fmaxf (aabb.h:33-43)
+inline aabb surroundingBox(const aabb& p, const aabb& q) {
+  aabb u;
+  for (int k = 0; k < 3; ++k) {
+    u.minimum(k) = fminf(p.minimum(k), q.minimum(k));
+    u.maximum(k) = fmaxf(p.maximum(k), q.maximum(k));
+  }
+  return u;
 }
+
 #endif

@@ -273,7 +273,7 @@ int envInt(const char* name, int dflt) {
 }
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
-  return (size_t)(ctx->scene.stackDepth + 3 * maxBounce) * 256 * sizeof(int32_t);
+  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce) * 256 * sizeof(int32_t);
 }
 
 }  // namespace

@@ -34,7 +34,7 @@
 
 #define SRT_BLOCK 256
 #ifndef SRT_RENDER_WAVES_PER_SIMD
-#define SRT_RENDER_WAVES_PER_SIMD 4
+#define SRT_RENDER_WAVES_PER_SIMD 5
 #endif
 
 namespace {
@@ -618,9 +618,10 @@ enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3 };
 template <bool CLOSEST, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
-  // per-thread LDS slots, [slot][thread]: stackDepth traversal slots, then 3*maxBounce attenuation floats
+  // per-thread LDS slots, [slot][thread]: stackDepth+1 traversal slots (one spare for the node step's
+  // unconditional store), then 3*maxBounce attenuation floats
   int32_t* stack = lds + threadIdx.x;
-  float* attStack = reinterpret_cast<float*>(lds + a.scene.stackDepth * SRT_BLOCK + threadIdx.x);
+  float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 1) * SRT_BLOCK + threadIdx.x);
   const int lane = threadIdx.x & 63;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
@@ -654,18 +655,21 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
   bool rayFast = false;
 
-  // next pending reference after the current subtree is done; ends the traversal when none is left
+  // next pending reference after the current subtree is done; ends the traversal when none is left.
+  // Written with selects rather than nested branches: every divergent `if` costs the wave half a
+  // dozen scalar exec-mask instructions, and the scalar unit is shared by the CU's four SIMDs.
   auto popNext = [&]() {
-    if (sp > 0) {
-      sp--;
-      cur = stack[sp * SRT_BLOCK];
-    } else if (++w < sc.numWorld) {
-      cur = sc.world[w];
-    } else {
-      cur = SRT_REF_DONE;
+    const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
+    const bool havePending = sp > 0;
+    sp -= havePending ? 1 : 0;
+    int next = top;
+    if (!havePending) {  // once per ray: next root of the world list, or done
+      next = SRT_REF_DONE;
+      if (++w < sc.numWorld) next = sc.world[w];
     }
-    mode = (cur == SRT_REF_DONE) ? M_SHADE : (cur >= 0 ? M_NODE : M_PRIM);
-    if (cur == SRT_REF_DONE) hasRay = true;
+    cur = next;
+    hasRay = hasRay || (next == SRT_REF_DONE);
+    mode = (next == SRT_REF_DONE) ? M_SHADE : (next >= 0 ? M_NODE : M_PRIM);
   };
 
   for (;;) {
@@ -708,18 +712,22 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           } else {
             hitBox = boxHit(n0, n1, ray, a.tMin, closest);
           }
-          if (hitBox) {
-            if (COUNT) cBox++;
-            int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-            if (right != left) {
-              stack[sp * SRT_BLOCK] = right;
-              sp++;
-            }
-            cur = left;
-            mode = cur >= 0 ? M_NODE : M_PRIM;
-          } else {
-            popNext();
+          if (COUNT && hitBox) cBox++;
+          // descend left and leave right pending, or take the next pending reference (selects, see popNext)
+          const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
+          stack[sp * SRT_BLOCK] = right;  // slot sp is free; it only becomes live if sp is bumped below
+          const bool push = hitBox && right != left;
+          const bool pop = !hitBox && sp > 0;
+          const bool exhausted = !hitBox && sp == 0;
+          sp += (push ? 1 : 0) - (pop ? 1 : 0);
+          cur = hitBox ? left : top;
+          if (exhausted) {  // once per ray
+            cur = SRT_REF_DONE;
+            if (++w < sc.numWorld) cur = sc.world[w];
           }
+          hasRay = hasRay || (cur == SRT_REF_DONE);
+          mode = (cur == SRT_REF_DONE) ? M_SHADE : (cur >= 0 ? M_NODE : M_PRIM);
         }
       } while (--budget > 0 && __popcll(__ballot(mode == M_NODE)) >= keep);
     } else if (pick == M_PRIM) {

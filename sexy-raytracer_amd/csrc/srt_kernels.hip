@@ -250,22 +250,22 @@ __device__ __forceinline__ V3 sphereCenter(const float4* sp, float4 s0, float4 s
   return c0;
 }
 
-// sphere.h:54-73 on loaded values: c = centre at the ray's time, radius
+// sphere.h:54-73 on loaded values: c = centre at the ray's time, radius.  Straight-line form of the
+// reference's early returns (same comparisons, same NaN behaviour): the lanes of a wave are at
+// different spheres/triangles anyway, so early exits only cost scalar exec-mask bookkeeping.
 __device__ __forceinline__ bool sphereHitV(V3 center, float radius, const Ray& r, float a, float tMin, float tMax,
                                            float& tOut) {
   V3 oc = r.o - center;
   float halfB = dot3(oc, r.d);
   float c = lenSq(oc) - radius * radius;
   float disc = halfB * halfB - a * c;
-  if (disc < 0.0f) return false;
   float sqrtd = sqrtf(disc);
-  float root = (-halfB - sqrtd) / a;
-  if (root < tMin || root > tMax) {
-    root = (-halfB + sqrtd) / a;
-    if (root < tMin || root > tMax) return false;
-  }
-  tOut = root;
-  return true;
+  float root1 = (-halfB - sqrtd) / a;
+  float root2 = (-halfB + sqrtd) / a;
+  const bool out1 = root1 < tMin || root1 > tMax;
+  const bool out2 = root2 < tMin || root2 > tMax;
+  tOut = out1 ? root2 : root1;
+  return !(disc < 0.0f) && !(out1 && out2);
 }
 __device__ __forceinline__ bool sphereHit(const float4* sp, const Ray& r, float a, float tMin, float tMax, float& tOut) {
   float4 s0 = sp[0], s1 = sp[1];
@@ -280,22 +280,19 @@ __device__ __forceinline__ bool triHitV(float4 q0, float4 q1, float4 q2, const R
   V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
   V3 n = mk(q0.w, q1.w, q2.w);
   float NdotDir = dot3(n, r.d);
-  if (fabsf(NdotDir) < SRT_EPS) return false;
-  if (NdotDir > 0) return false;  // dot(dir, n) has the same bits as dot(n, dir)
+  // model.h:119-123: parallel, then back-face (dot(dir, n) has the same bits as dot(n, dir))
+  bool ok = !(fabsf(NdotDir) < SRT_EPS) && !(NdotDir > 0);
   float d = -dot3(n, v0);
   float t = -(dot3(n, r.o) + d) / NdotDir;
-  if (t < tMin) return false;
-  if (CLOSEST && t > tMax) return false;
+  ok = ok && !(t < tMin);
+  if (CLOSEST) ok = ok && !(t > tMax);
   V3 p = r.o + t * r.d;
-  V3 c;
-  c = cross3(v1 - v0, p - v0);
-  if (dot3(n, c) < 0) return false;
-  c = cross3(v2 - v1, p - v1);
-  if (dot3(n, c) < 0) return false;
-  c = cross3(v0 - v2, p - v2);
-  if (dot3(n, c) < 0) return false;
+  // the three inside-edge tests (model.h:135-154); a NaN passes, as in the reference
+  ok = ok && !(dot3(n, cross3(v1 - v0, p - v0)) < 0);
+  ok = ok && !(dot3(n, cross3(v2 - v1, p - v1)) < 0);
+  ok = ok && !(dot3(n, cross3(v0 - v2, p - v2)) < 0);
   tOut = t;
-  return true;
+  return ok;
 }
 template <bool CLOSEST>
 __device__ __forceinline__ bool triHit(const float4* tr, const Ray& r, float tMin, float tMax, float& tOut) {

@@ -34,6 +34,10 @@ enum { SRT_MAT_PBR = 0, SRT_MAT_METAL = 1, SRT_MAT_DIELECTRIC = 2, SRT_MAT_LIGHT
 /* texture.h: solidColor :18, checker :34, imagePNG/image3bpp :109/:54 */
 enum { SRT_TEX_SOLID = 0, SRT_TEX_CHECKER = 1, SRT_TEX_IMAGE = 2 };
 enum { SRT_WORLD_PRIM = 0, SRT_WORLD_BVH = 1 };
+/* who builds an SRT_WORLD_BVH item's tree when the caller supplies none:
+ * REFERENCE = bvh.h:55-95 on the host (the tree FAITHFUL traversal semantics are defined on);
+ * LBVH = a linear BVH built on the device, for SRT_TRAVERSE_CLOSEST rendering of large scenes. */
+enum { SRT_BUILDER_REFERENCE = 0, SRT_BUILDER_LBVH = 1 };
 /* traversal semantics: FAITHFUL = bvh.h:97-105 order with triangle::hit's
  * missing tMax test (model.h:128); CLOSEST adds the t < closest test. */
 enum { SRT_TRAVERSE_FAITHFUL = 0, SRT_TRAVERSE_CLOSEST = 1 };
@@ -84,6 +88,8 @@ typedef struct SrtWorldItem {
   float time0, time1;
   int32_t numNodes;
   const struct SrtBvhNode* nodes;
+  int32_t builder; /* SRT_BUILDER_* (ignored when nodes != NULL) */
+  int32_t pad;
 } SrtWorldItem;
 
 /* material.h.  Field use per type:

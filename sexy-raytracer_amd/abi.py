@@ -11,6 +11,7 @@ SRT_MAT_PBR, SRT_MAT_METAL, SRT_MAT_DIELECTRIC, SRT_MAT_LIGHT = 0, 1, 2, 3
 SRT_TEX_SOLID, SRT_TEX_CHECKER, SRT_TEX_IMAGE = 0, 1, 2
 SRT_WORLD_PRIM, SRT_WORLD_BVH = 0, 1
 SRT_TRAVERSE_FAITHFUL, SRT_TRAVERSE_CLOSEST = 0, 1
+SRT_BUILDER_REFERENCE, SRT_BUILDER_LBVH = 0, 1
 SRT_TILE_W = SRT_TILE_H = 8
 SRT_TILE_PIXELS = 64
 SRT_NO_HIT = -1
@@ -33,7 +34,7 @@ class SrtPrimRef(C.Structure):
 
 class SrtWorldItem(C.Structure):
     _fields_ = [("kind", i32), ("first", i32), ("count", i32), ("time0", f32), ("time1", f32),
-                ("numNodes", i32), ("nodes", C.c_void_p)]
+                ("numNodes", i32), ("nodes", C.c_void_p), ("builder", i32), ("pad", i32)]
 
 
 class SrtMaterialIn(C.Structure):
@@ -233,10 +234,10 @@ class SceneBuilder:
         return self.num_prims - n
 
     # ---- world (main.cpp:146)
-    def world_bvh(self, first=0, count=None, time0=0.0, time1=1.0):
+    def world_bvh(self, first=0, count=None, time0=0.0, time1=1.0, builder=SRT_BUILDER_REFERENCE):
         if count is None:
             count = self.num_prims - first
-        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, 0, None))
+        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, 0, None, builder, 0))
 
     def world_prebuilt(self, nodes, first=0, count=None, time0=0.0, time1=1.0):
         """A caller-built tree (NODE_DTYPE array, pre-order, child refs as in SrtBvhNode)."""
@@ -244,10 +245,10 @@ class SceneBuilder:
             count = self.num_prims - first
         nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self._prebuilt = getattr(self, "_prebuilt", []) + [nodes]
-        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, len(nodes), nodes.ctypes.data))
+        self.world.append(SrtWorldItem(SRT_WORLD_BVH, first, count, time0, time1, len(nodes), nodes.ctypes.data, 0, 0))
 
     def world_prim(self, prim):
-        self.world.append(SrtWorldItem(SRT_WORLD_PRIM, prim, 1, 0.0, 0.0, 0, None))
+        self.world.append(SrtWorldItem(SRT_WORLD_PRIM, prim, 1, 0.0, 0.0, 0, None, 0, 0))
 
     def desc(self):
         def arr(ctype, items):

@@ -26,6 +26,8 @@ int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksP
 int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes, int base,
+                   int* depthOut);
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
@@ -220,6 +222,9 @@ struct SrtContext {
   bool haveScene = false, haveCamera = false;
   // host copies for srtGetBvh
   std::vector<std::vector<SrtBvhNode>> itemNodes;
+  struct DeviceTree { int32_t base = -1, count = 0; };
+  std::vector<DeviceTree> itemDeviceTree;  // LBVH items: where their nodes live in scene.nodes
+  std::vector<int32_t> hostTriPrimId, hostSphPrimId;
   int bvhDepth = 0;
   // work areas
   int32_t* dQueue = nullptr;
@@ -419,6 +424,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
   HIP_OK(ctx, hipSetDevice(ctx->device));
   freeScene(ctx);
   ctx->itemNodes.clear();
+  ctx->itemDeviceTree.clear();
   ctx->bvhDepth = 0;
 
   if (validateScene(ctx, d)) return 1;
@@ -480,8 +486,18 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
   for (int w = 0; w < d->numWorld; ++w) {
     const SrtWorldItem& it = d->world[w];
     ctx->itemNodes.emplace_back();
+    ctx->itemDeviceTree.emplace_back();
     if (it.kind == SRT_WORLD_PRIM) {
       world.push_back(devRef(~it.first));
+      continue;
+    }
+    if (!it.nodes && it.builder == SRT_BUILDER_LBVH) {
+      // device build (srt_lbvh.hip) after the primitive arrays are uploaded: reserve the node slots
+      int32_t base = (int32_t)(nodes.size() / 2), cnt = std::max(it.count - 1, 1);
+      nodes.resize(nodes.size() + 2 * (size_t)cnt, make_float4(0, 0, 0, 0));
+      ctx->itemDeviceTree.back().base = base;
+      ctx->itemDeviceTree.back().count = cnt;
+      world.push_back(base);
       continue;
     }
     Builder b;
@@ -557,8 +573,40 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
       uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) ||
       uploadVec(ctx, texs, &s.textures) || uploadVec(ctx, texels, &s.texels, 64))
     return 1;
+  ctx->hostTriPrimId = triPrimId;
+  ctx->hostSphPrimId = sphPrimId;
+  // device-built trees
+  bool lbvhCertificate = true;
+  for (int w = 0; w < d->numWorld; ++w) {
+    const SrtContext::DeviceTree& dt = ctx->itemDeviceTree[w];
+    if (dt.base < 0) continue;
+    const SrtWorldItem& it = d->world[w];
+    std::vector<int32_t> refs(it.count);
+    Builder pb;
+    pb.d = d;
+    for (int i = 0; i < it.count; ++i) {
+      refs[i] = devRef(~(it.first + i));
+      // node boxes of this tree are unions of primitive boxes: extend fastDiv's coordinate certificate to them
+      Box bx = pb.primBox(it.first + i, it.time0, it.time1);
+      for (int k = 0; k < 3; ++k)
+        for (float c : {bx.mn[k], bx.mx[k]}) {
+          float ac = fabsf(c);
+          if (!(c == 0.0f || (ac >= 0x1p-77f && ac <= 0x1p30f))) lbvhCertificate = false;
+        }
+    }
+    int32_t* dRefs = nullptr;
+    HIP_OK(ctx, hipMalloc((void**)&dRefs, refs.size() * sizeof(int32_t)));
+    hipError_t ce = hipMemcpy(dRefs, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    int depth = 0;
+    int rc = ce != hipSuccess ? (int)ce : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), dt.base, &depth);
+    (void)hipFree(dRefs);
+    if (rc) return fail(ctx, "device BVH build of world item %d failed: %s", w, hipGetErrorString((hipError_t)rc));
+    stackDepth = std::max(stackDepth, depth);
+    ctx->bvhDepth = std::max(ctx->bvhDepth, depth);
+  }
   s.numWorld = (int32_t)world.size();
   s.stackDepth = stackDepth;
+  const bool lbvhOk = lbvhCertificate;
   s.numNodes = (int32_t)(nodes.size() / 2);
   s.numTris = d->numTriangles;
   s.numSpheres = d->numSpheres;
@@ -569,6 +617,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
       float ac = fabsf(c);
       if (!(c == 0.0f || (ac >= 0x1p-77f && ac <= 0x1p30f))) s.fastDivScene = 0;
     }
+  if (!lbvhOk) s.fastDivScene = 0;
   ctx->haveScene = true;
   return 0;
 }
@@ -597,6 +646,27 @@ int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t ca
 int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) {
   if (!ctx || !count) return 1;
   if (item < 0 || item >= (int32_t)ctx->itemNodes.size()) return fail(ctx, "srtGetBvh: item %d out of range", item);
+  if (ctx->itemDeviceTree[item].base >= 0 && ctx->itemNodes[item].empty()) {
+    // device-built tree: read it back once, converting child refs to the host convention
+    const auto& dt = ctx->itemDeviceTree[item];
+    std::vector<float4> raw((size_t)dt.count * 2);
+    HIP_OK(ctx, hipMemcpy(raw.data(), ctx->scene.nodes + 2 * (size_t)dt.base, raw.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    auto& out = ctx->itemNodes[item];
+    out.resize(dt.count);
+    auto conv = [&](float bits) -> int32_t {
+      int32_t r;
+      memcpy(&r, &bits, 4);
+      if (r >= 0) return r - dt.base;
+      int32_t pr = ~r;
+      return ~((pr & 1) ? ctx->hostSphPrimId[pr >> 1] : ctx->hostTriPrimId[pr >> 1]);
+    };
+    for (int i = 0; i < dt.count; ++i) {
+      out[i].bmin[0] = raw[2 * i].x; out[i].bmin[1] = raw[2 * i].y; out[i].bmin[2] = raw[2 * i].z;
+      out[i].bmax[0] = raw[2 * i + 1].x; out[i].bmax[1] = raw[2 * i + 1].y; out[i].bmax[2] = raw[2 * i + 1].z;
+      out[i].left = conv(raw[2 * i].w);
+      out[i].right = conv(raw[2 * i + 1].w);
+    }
+  }
   const auto& v = ctx->itemNodes[item];
   *count = (int32_t)v.size();
   if (nodes) {

@@ -1,0 +1,260 @@
+// srt_lbvh.hip -- device-side BVH build: a linear BVH (Morton order + Karras'
+// parallel hierarchy + bottom-up refit) over the primitives already resident in HBM.
+//
+// This is NOT the reference's tree: bvh.h:55-95 builds a random-axis median split whose shape the
+// FAITHFUL traversal semantics depend on.  A device-built tree is for
+// SRT_TRAVERSE_CLOSEST rendering of large scenes, where the closest hit does not depend on the tree
+// (the reference's tree needs 2 400+ node visits per ray on a 10 M-triangle soup).
+// Primitive boxes follow the reference's boundingBox rules (model.h:183-212 incl. the +-1e-4 padding
+// of flat axes; sphere.h:85-94 incl. motion over [time0, time1]).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "srt_device.h"
+
+namespace {
+
+__device__ __forceinline__ int orderedInt(float f) {  // monotone float -> int for atomicMin/Max
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float orderedFloat(int i) {
+  int b = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+
+__device__ __forceinline__ void primBox(const DevScene& sc, int ref, float time0, float time1, float* mn, float* mx) {
+  int pr = ~ref;
+  if (pr & 1) {  // sphere.h:85-94
+    const float4* sp = sc.spheres + 3 * (pr >> 1);
+    float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    float c0[3] = {s0.x, s0.y, s0.z}, c1[3] = {s1.x, s1.y, s1.z};
+    bool moving = __float_as_int(s1.w) & (1 << 30);
+    for (int k = 0; k < 3; ++k) {
+      float a = c0[k], b = c0[k];
+      if (moving) {
+        a = c0[k] + ((time0 - s2.x) / (s2.y - s2.x)) * (c1[k] - c0[k]);
+        b = c0[k] + ((time1 - s2.x) / (s2.y - s2.x)) * (c1[k] - c0[k]);
+      }
+      mn[k] = fminf(a - s0.w, b - s0.w);
+      mx[k] = fmaxf(a + s0.w, b + s0.w);
+    }
+  } else {  // model.h:183-212
+    const float4* tr = sc.triTest + 3 * (pr >> 1);
+    float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+    float v[3][3] = {{q0.x, q0.y, q0.z}, {q1.x, q1.y, q1.z}, {q2.x, q2.y, q2.z}};
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = fminf(v[0][k], fminf(v[1][k], v[2][k]));
+      mx[k] = fmaxf(v[0][k], fmaxf(v[1][k], v[2][k]));
+      if (mn[k] == mx[k]) {
+        mn[k] -= 0.0001f;
+        mx[k] += 0.0001f;
+      }
+    }
+  }
+}
+
+// 1. per-primitive boxes + scene bounds of the centroids
+__global__ void lbvhPrimBoxes(DevScene sc, const int32_t* refs, int n, float time0, float time1, float4* boxMin,
+                              float4* boxMax, int* bounds /* 3 min, 3 max as ordered ints */) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mn[3], mx[3];
+  primBox(sc, refs[i], time0, time1, mn, mx);
+  boxMin[i] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+  boxMax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+  for (int k = 0; k < 3; ++k) {
+    float c = 0.5f * (mn[k] + mx[k]);
+    atomicMin(&bounds[k], orderedInt(c));
+    atomicMax(&bounds[3 + k], orderedInt(c));
+  }
+}
+
+__device__ __forceinline__ uint32_t expandBits(uint32_t v) {  // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+// 2. 30-bit Morton code of the centroid, made unique by the primitive's position
+__global__ void lbvhMorton(const float4* boxMin, const float4* boxMax, int n, const int* bounds, unsigned long long* keys,
+                           int* vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float lo[3] = {orderedFloat(bounds[0]), orderedFloat(bounds[1]), orderedFloat(bounds[2])};
+  float hi[3] = {orderedFloat(bounds[3]), orderedFloat(bounds[4]), orderedFloat(bounds[5])};
+  float4 a = boxMin[i], b = boxMax[i];
+  float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    float ext = hi[k] - lo[k];
+    float u = ext > 0.0f ? (c[k] - lo[k]) / ext : 0.0f;
+    q[k] = (uint32_t)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+  }
+  uint32_t m = (expandBits(q[0]) << 2) | (expandBits(q[1]) << 1) | expandBits(q[2]);
+  keys[i] = ((unsigned long long)m << 32) | (unsigned)i;
+  vals[i] = i;
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  return __clzll((long long)(keys[i] ^ keys[j]));  // keys are unique
+}
+
+// 4. Karras 2012: internal node i covers a contiguous key range; children are internal nodes or leaves.
+// child encoding here: >= 0 internal node, < 0 leaf ~sortedPosition
+__global__ void lbvhHierarchy(const unsigned long long* keys, int n, int* left, int* right, int* parentInternal,
+                              int* parentLeaf) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  int j = i + l * d;
+  int dnode = delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t == 1) break;
+  }
+  int gamma = i + s * d + min(d, 0);
+  int lo = min(i, j), hi = max(i, j);
+  int lc = (lo == gamma) ? ~gamma : gamma;
+  int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  left[i] = lc;
+  right[i] = rc;
+  if (lc >= 0) parentInternal[lc] = i; else parentLeaf[~lc] = i;
+  if (rc >= 0) parentInternal[rc] = i; else parentLeaf[~rc] = i;
+  if (i == 0) parentInternal[0] = -1;
+}
+
+// 5+6. bottom-up refit: the second thread to arrive at a node owns it; emits the node record.
+// 7. each leaf also reports its depth.
+__global__ void lbvhFit(const int* left, const int* right, const int* parentInternal, const int* parentLeaf,
+                        const int* sortedVals, const int32_t* refs, const float4* boxMin, const float4* boxMax, int n,
+                        float4* nodeMin, float4* nodeMax, int* arrived, float4* outNodes, int base, int* maxDepth) {
+  int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int depth = 1;
+  int node = parentLeaf[leaf];
+  while (node >= 0) {
+    depth++;
+    __threadfence();
+    if (atomicAdd(&arrived[node], 1) == 0) {
+      // first arrival: the sibling subtree is not finished; but keep counting depth to the root
+      int up = parentInternal[node];
+      while (up >= 0) {
+        depth++;
+        up = parentInternal[up];
+      }
+      break;
+    }
+    __threadfence();
+    float4 mnL, mxL, mnR, mxR;
+    int lc = left[node], rc = right[node];
+    int lref, rref;
+    if (lc >= 0) {
+      mnL = nodeMin[lc];
+      mxL = nodeMax[lc];
+      lref = lc + base;
+    } else {
+      int p = sortedVals[~lc];
+      mnL = boxMin[p];
+      mxL = boxMax[p];
+      lref = refs[p];
+    }
+    if (rc >= 0) {
+      mnR = nodeMin[rc];
+      mxR = nodeMax[rc];
+      rref = rc + base;
+    } else {
+      int p = sortedVals[~rc];
+      mnR = boxMin[p];
+      mxR = boxMax[p];
+      rref = refs[p];
+    }
+    float4 mn = make_float4(fminf(mnL.x, mnR.x), fminf(mnL.y, mnR.y), fminf(mnL.z, mnR.z), 0.0f);
+    float4 mx = make_float4(fmaxf(mxL.x, mxR.x), fmaxf(mxL.y, mxR.y), fmaxf(mxL.z, mxR.z), 0.0f);
+    nodeMin[node] = mn;
+    nodeMax[node] = mx;
+    outNodes[2 * (size_t)(base + node) + 0] = make_float4(mn.x, mn.y, mn.z, __int_as_float(lref));
+    outNodes[2 * (size_t)(base + node) + 1] = make_float4(mx.x, mx.y, mx.z, __int_as_float(rref));
+    node = parentInternal[node];
+  }
+  atomicMax(maxDepth, depth);
+}
+
+// one primitive: a single-object leaf like the reference's (left == right, bvh.h:67-69)
+__global__ void lbvhSingle(DevScene sc, const int32_t* refs, float time0, float time1, float4* outNodes, int base) {
+  float mn[3], mx[3];
+  primBox(sc, refs[0], time0, time1, mn, mx);
+  outNodes[2 * (size_t)base + 0] = make_float4(mn[0], mn[1], mn[2], __int_as_float(refs[0]));
+  outNodes[2 * (size_t)base + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(refs[0]));
+}
+
+}  // namespace
+
+// Builds the tree of one world item into outNodes[base .. base + max(n-1, 1)).  dRefs: n device
+// primitive refs.  Blocking.  Returns 0 and the tree depth (root = 1), or a hipError_t.
+extern "C" int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
+                              int base, int* depthOut) {
+  if (n < 1) return (int)hipErrorInvalidValue;
+  if (n == 1) {
+    hipLaunchKernelGGL(lbvhSingle, dim3(1), dim3(1), 0, nullptr, *sc, dRefs, time0, time1, outNodes, base);
+    *depthOut = 1;
+    return (int)hipDeviceSynchronize();
+  }
+  const size_t N = (size_t)n;
+  char* pool = nullptr;
+  size_t sortBytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                           (int*)nullptr, (int*)nullptr, N, 0, 64, nullptr);
+  if (e != hipSuccess) return (int)e;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+  size_t oBoxMin = take(N * 16), oBoxMax = take(N * 16), oNodeMin = take(N * 16), oNodeMax = take(N * 16);
+  size_t oKeys = take(N * 8), oKeys2 = take(N * 8), oVals = take(N * 4), oVals2 = take(N * 4);
+  size_t oLeft = take(N * 4), oRight = take(N * 4), oParI = take(N * 4), oParL = take(N * 4), oArr = take(N * 4);
+  size_t oBounds = take(64), oDepth = take(64), oSort = take(sortBytes);
+  e = hipMalloc((void**)&pool, off);
+  if (e != hipSuccess) return (int)e;
+  auto P = [&](size_t o) { return pool + o; };
+  int initBounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int rc = 0;
+  do {
+    if ((e = hipMemcpy(P(oBounds), initBounds, sizeof initBounds, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = hipMemset(P(oArr), 0, N * 4)) != hipSuccess) break;
+    if ((e = hipMemset(P(oDepth), 0, 4)) != hipSuccess) break;
+    const int B = 256, G = (n + B - 1) / B;
+    hipLaunchKernelGGL(lbvhPrimBoxes, dim3(G), dim3(B), 0, nullptr, *sc, dRefs, n, time0, time1, (float4*)P(oBoxMin),
+                       (float4*)P(oBoxMax), (int*)P(oBounds));
+    hipLaunchKernelGGL(lbvhMorton, dim3(G), dim3(B), 0, nullptr, (const float4*)P(oBoxMin), (const float4*)P(oBoxMax), n,
+                       (const int*)P(oBounds), (unsigned long long*)P(oKeys), (int*)P(oVals));
+    e = rocprim::radix_sort_pairs(P(oSort), sortBytes, (unsigned long long*)P(oKeys), (unsigned long long*)P(oKeys2),
+                                  (int*)P(oVals), (int*)P(oVals2), N, 0, 64, nullptr);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(lbvhHierarchy, dim3(G), dim3(B), 0, nullptr, (const unsigned long long*)P(oKeys2), n,
+                       (int*)P(oLeft), (int*)P(oRight), (int*)P(oParI), (int*)P(oParL));
+    hipLaunchKernelGGL(lbvhFit, dim3(G), dim3(B), 0, nullptr, (const int*)P(oLeft), (const int*)P(oRight),
+                       (const int*)P(oParI), (const int*)P(oParL), (const int*)P(oVals2), dRefs,
+                       (const float4*)P(oBoxMin), (const float4*)P(oBoxMax), n, (float4*)P(oNodeMin), (float4*)P(oNodeMax),
+                       (int*)P(oArr), outNodes, base, (int*)P(oDepth));
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if ((e = hipMemcpy(depthOut, P(oDepth), 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+  } while (0);
+  rc = (int)e;
+  (void)hipFree(pool);
+  return rc;
+}

@@ -133,7 +133,7 @@ def scene_masterchief(with_spheres=True):
     return sb
 
 
-def scene_soup(num_triangles, seed=7, extent=6.0, size=0.08, with_ground=True):
+def scene_soup(num_triangles, seed=7, extent=6.0, size=0.08, with_ground=True, builder=0):
     """Synthetic seeded triangle soup (SURVEY 8d 'Synthetic'): working sets beyond the caches."""
     rng = np.random.default_rng(seed)
     sb = SceneBuilder()
@@ -147,7 +147,7 @@ def scene_soup(num_triangles, seed=7, extent=6.0, size=0.08, with_ground=True):
     sb.add_triangles(pos, uv, idx, mat)
     if with_ground:
         _ground(sb)
-    sb.world_bvh(0, None, 0.0, 1.0)
+    sb.world_bvh(0, None, 0.0, 1.0, builder=builder)
     return sb
 
 

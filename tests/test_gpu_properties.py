@@ -255,3 +255,76 @@ def test_progressive_passes_checkpoint_and_resume(tmp_path, ctx, abi, srt, camer
     want, want_rgba = ctx.render_image(abi.default_render_params(160, 90, 16, 4, seed=21, spp_chunks=2))
     assert pr2.accum.tobytes() == want.tobytes()
     assert np.array_equal(pr2.image_rgba8(), want_rgba)
+
+
+def _tree_checks(nodes, num_prims):
+    """A valid binary tree over num_prims leaves: every primitive referenced once, every internal
+    node except the root referenced once, every box the union of its children's boxes."""
+    n = len(nodes)
+    assert n == max(num_prims - 1, 1)
+    refs = np.concatenate([nodes["left"], nodes["right"]]) if num_prims > 1 else nodes["left"]
+    prims = ~refs[refs < 0]
+    assert sorted(prims.tolist()) == list(range(num_prims))
+    inner = refs[refs >= 0]
+    assert sorted(inner.tolist()) == list(range(1, n))
+    return True
+
+
+def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera):
+    """the device-built linear BVH.  The closest hit does not depend on the tree, so
+    CLOSEST traversal of the device tree must reproduce the oracle's brute-force closest hit bit for
+    bit, and CLOSEST renders through the device tree and through the reference tree must agree."""
+    n = 30000
+    sb = srt.scenes.scene_soup(n, seed=5, builder=abi.SRT_BUILDER_LBVH)
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    nodes = ctx.bvh(0)
+    assert _tree_checks(nodes, n + 1)
+    # boxes: parents enclose children exactly (union), checked top-down on the node array
+    for child in ("left", "right"):
+        c = nodes[child]
+        m = c >= 0
+        assert (nodes["bmin"][m] <= nodes["bmin"][c[m]]).all() and (nodes["bmax"][m] >= nodes["bmax"][c[m]]).all()
+    assert 15 <= ctx.bvh_depth() <= 64
+    rng = np.random.default_rng(9)
+    rays = np.zeros(40000, abi.RAY_DTYPE)
+    rays["o"] = (0.0, 3.0, 5.0)
+    rays["d"] = rng.normal(size=(len(rays), 3)).astype(np.float32)
+    rays["tMin"], rays["tMax"] = 0.001, np.inf
+    got = ctx.trace(rays, abi.SRT_TRAVERSE_CLOSEST)
+    want = oracle.OracleScene(sb).trace(rays, abi.SRT_TRAVERSE_CLOSEST)  # brute force over all primitives
+    assert np.array_equal(got["prim"] >= 0, want["prim"] >= 0)
+    m = want["prim"] >= 0
+    assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
+    assert (got["prim"][m] != want["prim"][m]).mean() < 1e-3  # exact ties only
+    p = abi.default_render_params(160, 90, 4, 4, seed=3, traversal=abi.SRT_TRAVERSE_CLOSEST)
+    acc_dev, _ = ctx.render_image(p)
+    ctx.upload_scene(srt.scenes.scene_soup(n, seed=5))  # same scene, the reference's tree
+    acc_ref, _ = ctx.render_image(p)
+    same = (acc_dev.view(np.uint32) == acc_ref.view(np.uint32)).all(axis=-1)
+    assert same.mean() > 0.999
+
+
+def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera):
+    for count in (1, 2, 3, 37):
+        sb = abi.SceneBuilder()
+        m = sb.metal((0.7, 0.6, 0.5), 0.1)
+        rng = np.random.default_rng(count)
+        for _ in range(count):
+            c = rng.uniform(-3, 3, 3) + np.array([0, 3, -1])
+            sb.add_sphere(tuple(c), 0.5, m, center1=tuple(c + rng.uniform(-0.4, 0.4, 3)), time0=0.0, time1=1.0)
+        sb.world_bvh(0, None, 0.0, 1.0, builder=abi.SRT_BUILDER_LBVH)
+        ctx.upload_scene(sb)
+        ctx.set_camera(camera)
+        assert _tree_checks(ctx.bvh(0), count)
+        rng = np.random.default_rng(1)
+        rays = np.zeros(5000, abi.RAY_DTYPE)
+        rays["o"] = (0.0, 3.0, 5.0)
+        rays["d"] = rng.normal(size=(len(rays), 3)).astype(np.float32)
+        rays["time"] = rng.random(len(rays)).astype(np.float32)
+        rays["tMin"], rays["tMax"] = 0.001, np.inf
+        got = ctx.trace(rays, abi.SRT_TRAVERSE_CLOSEST)
+        want = oracle.OracleScene(sb).trace(rays, abi.SRT_TRAVERSE_CLOSEST)
+        assert np.array_equal(got["prim"], want["prim"])
+        mm = want["prim"] >= 0
+        assert np.array_equal(got["t"][mm].view(np.uint32), want["t"][mm].view(np.uint32))

@@ -26,8 +26,8 @@ int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksP
 int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
-int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes, int base,
-                   int* depthOut);
+int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
+                   uint8_t* outAxis, int base, int* depthOut);
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
@@ -116,6 +116,7 @@ Box triangleBox(const SrtTriangleIn& t) {  // model.h:183-212
 struct BuildNode {
   Box box;
   int32_t left, right;  // >= 0 node, < 0 ~primListIndex
+  uint8_t axis = 3;     // split axis (left child = lower box minimum on it), 3 = unknown
 };
 
 struct Builder {
@@ -158,12 +159,15 @@ struct Builder {
       std::sort(objects.begin() + start, objects.begin() + end, comparator);
       size_t mid = start + span / 2;
       maxPending = std::max(maxPending, pending + 1);
+      // capacity must hold for either visiting order (CLOSEST descends into the near child first and
+      // leaves the other one pending), so both children are entered with one more pending entry
       left = build(start, mid, pending + 1);
-      right = build(mid, end, pending);
+      right = build(mid, end, pending + 1);
     }
     BuildNode& n = nodes[me];
     n.left = left;
     n.right = right;
+    n.axis = (uint8_t)axis;
     n.box = surrounding(childBox(left), childBox(right));  // bvh.h:88-94
     return me;
   }
@@ -187,7 +191,7 @@ void buildItem(const SrtSceneDesc* d, const SrtWorldItem& it, Builder& b) {
       const bool two = n.right != n.left;
       if (two) b.maxPending = std::max(b.maxPending, pending[i] + 1);
       if (n.left >= 0) pending[n.left] = pending[i] + (two ? 1 : 0);
-      if (two && n.right >= 0) pending[n.right] = pending[i];
+      if (two && n.right >= 0) pending[n.right] = pending[i] + 1;  // either child may be the one left pending
     }
     return;
   }
@@ -481,6 +485,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
 
   // ---- world: build each bvhNode (consumes the global generator in scene order)
   std::vector<float4> nodes;
+  std::vector<uint8_t> nodeAxis;
   std::vector<int32_t> world;
   int stackDepth = 0;
   for (int w = 0; w < d->numWorld; ++w) {
@@ -495,6 +500,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
       // device build (srt_lbvh.hip) after the primitive arrays are uploaded: reserve the node slots
       int32_t base = (int32_t)(nodes.size() / 2), cnt = std::max(it.count - 1, 1);
       nodes.resize(nodes.size() + 2 * (size_t)cnt, make_float4(0, 0, 0, 0));
+      nodeAxis.resize(nodeAxis.size() + cnt, 3);
       ctx->itemDeviceTree.back().base = base;
       ctx->itemDeviceTree.back().count = cnt;
       world.push_back(base);
@@ -519,6 +525,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
       memcpy(&rf, &r, 4);
       nodes.push_back(make_float4(n.box.mn[0], n.box.mn[1], n.box.mn[2], lf));
       nodes.push_back(make_float4(n.box.mx[0], n.box.mx[1], n.box.mx[2], rf));
+      nodeAxis.push_back(n.axis);
     }
     world.push_back(base);
     stackDepth = std::max(stackDepth, b.maxPending);
@@ -568,7 +575,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
 
   DevScene& s = ctx->scene;
   memset(&s, 0, sizeof s);
-  if (uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
+  if (uploadVec(ctx, nodeAxis, &s.nodeAxis, 64) || uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
       uploadVec(ctx, spheres, &s.spheres) || uploadVec(ctx, triPrimId, &s.triPrimId) ||
       uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) ||
       uploadVec(ctx, texs, &s.textures) || uploadVec(ctx, texels, &s.texels, 64))
@@ -598,7 +605,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     HIP_OK(ctx, hipMalloc((void**)&dRefs, refs.size() * sizeof(int32_t)));
     hipError_t ce = hipMemcpy(dRefs, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     int depth = 0;
-    int rc = ce != hipSuccess ? (int)ce : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), dt.base, &depth);
+    int rc = ce != hipSuccess ? (int)ce : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis), dt.base, &depth);
     (void)hipFree(dRefs);
     if (rc) return fail(ctx, "device BVH build of world item %d failed: %s", w, hipGetErrorString((hipError_t)rc));
     stackDepth = std::max(stackDepth, depth);

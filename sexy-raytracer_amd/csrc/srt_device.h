@@ -44,6 +44,9 @@ struct DevScene {
   const float4* triShade;
   // 3 x float4 per sphere: (c0.xyz, radius) (c1.xyz, material | moving<<30) (t0, t1, -, -)   -- 16..48 B / test
   const float4* spheres;
+  // 1 byte per node: the axis its children are split on (left = lower side), 3 = unknown.  Read only by
+  // SRT_TRAVERSE_CLOSEST, which visits the nearer child first; FAITHFUL keeps bvh.h's left-then-right.
+  const uint8_t* nodeAxis;
   const int32_t* triPrimId;  // device index -> index into the scene's prims[] list
   const int32_t* sphPrimId;
   const int32_t* world;  // refs, world-list order

@@ -321,7 +321,16 @@ __device__ __forceinline__ int traverse(const DevScene& sc, const Ray& r, float 
         if (boxHit(n0, n1, r, tMin, closest)) {
           if (COUNT) cnt.boxPasses++;
           int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-          if (right != left) {
+          if (CLOSEST) {  // near child first (see the render kernel's node step)
+            const int axis = sc.nodeAxis[cur];
+            const float dAxis = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
+            if (axis < 3 && dAxis < 0.0f) {
+              const int tmp = left;
+              left = right;
+              right = tmp;
+            }
+          }
+          if (right != left && sp < sc.stackDepth) {  // capacity is guaranteed at upload (see srt_api.cpp Builder)
             stack[sp * SRT_BLOCK] = right;
             sp++;
           }
@@ -711,13 +720,25 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           }
           if (COUNT && hitBox) cBox++;
           // descend left and leave right pending, or take the next pending reference (selects, see popNext)
-          const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          if (CLOSEST) {
+            // the closest hit does not depend on the visiting order: take the child on the ray's near side
+            // first (left = lower side of the split axis) so that far subtrees get culled by `closest`
+            const int axis = sc.nodeAxis[cur];
+            const float dAxis = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
+            if (axis < 3 && dAxis < 0.0f) {
+              const int tmp = left;
+              left = right;
+              right = tmp;
+            }
+          }
           const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
           stack[sp * SRT_BLOCK] = right;  // slot sp is free; it only becomes live if sp is bumped below
           const bool push = hitBox && right != left;
           const bool pop = !hitBox && sp > 0;
           const bool exhausted = !hitBox && sp == 0;
           sp += (push ? 1 : 0) - (pop ? 1 : 0);
+          sp = min(sp, sc.stackDepth);  // capacity is guaranteed at upload; never index LDS beyond it regardless
           cur = hitBox ? left : top;
           if (exhausted) {  // once per ray
             cur = SRT_REF_DONE;

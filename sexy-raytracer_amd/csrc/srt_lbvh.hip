@@ -110,7 +110,7 @@ __device__ __forceinline__ int delta(const unsigned long long* keys, int n, int 
 // 4. Karras 2012: internal node i covers a contiguous key range; children are internal nodes or leaves.
 // child encoding here: >= 0 internal node, < 0 leaf ~sortedPosition
 __global__ void lbvhHierarchy(const unsigned long long* keys, int n, int* left, int* right, int* parentInternal,
-                              int* parentLeaf) {
+                              int* parentLeaf, uint8_t* outAxis, int base) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -136,6 +136,10 @@ __global__ void lbvhHierarchy(const unsigned long long* keys, int n, int* left, 
   if (lc >= 0) parentInternal[lc] = i; else parentLeaf[~lc] = i;
   if (rc >= 0) parentInternal[rc] = i; else parentLeaf[~rc] = i;
   if (i == 0) parentInternal[0] = -1;
+  // the children differ first in key bit 63 - dnode; Morton bits (key bits 32..61) interleave x,y,z with z
+  // lowest, and the left child holds the 0 side = the lower coordinate.  A tie broken by the index: unknown.
+  int bit = 63 - dnode;
+  outAxis[base + i] = bit >= 32 ? (uint8_t)(2 - ((bit - 32) % 3)) : (uint8_t)3;
 }
 
 // 5+6. bottom-up refit: the second thread to arrive at a node owns it; emits the node record.
@@ -207,7 +211,7 @@ __global__ void lbvhSingle(DevScene sc, const int32_t* refs, float time0, float 
 // Builds the tree of one world item into outNodes[base .. base + max(n-1, 1)).  dRefs: n device
 // primitive refs.  Blocking.  Returns 0 and the tree depth (root = 1), or a hipError_t.
 extern "C" int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
-                              int base, int* depthOut) {
+                              uint8_t* outAxis, int base, int* depthOut) {
   if (n < 1) return (int)hipErrorInvalidValue;
   if (n == 1) {
     hipLaunchKernelGGL(lbvhSingle, dim3(1), dim3(1), 0, nullptr, *sc, dRefs, time0, time1, outNodes, base);
@@ -245,7 +249,7 @@ extern "C" int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, f
                                   (int*)P(oVals), (int*)P(oVals2), N, 0, 64, nullptr);
     if (e != hipSuccess) break;
     hipLaunchKernelGGL(lbvhHierarchy, dim3(G), dim3(B), 0, nullptr, (const unsigned long long*)P(oKeys2), n,
-                       (int*)P(oLeft), (int*)P(oRight), (int*)P(oParI), (int*)P(oParL));
+                       (int*)P(oLeft), (int*)P(oRight), (int*)P(oParI), (int*)P(oParL), outAxis, base);
     hipLaunchKernelGGL(lbvhFit, dim3(G), dim3(B), 0, nullptr, (const int*)P(oLeft), (const int*)P(oRight),
                        (const int*)P(oParI), (const int*)P(oParL), (const int*)P(oVals2), dRefs,
                        (const float4*)P(oBoxMin), (const float4*)P(oBoxMax), n, (float4*)P(oNodeMin), (float4*)P(oNodeMax),

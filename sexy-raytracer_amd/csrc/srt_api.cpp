@@ -282,7 +282,7 @@ int envInt(const char* name, int dflt) {
 }
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
-  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce) * 256 * sizeof(int32_t);
+  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce + 3) * 256 * sizeof(int32_t);
 }
 
 }  // namespace
@@ -742,8 +742,9 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
   a.sppChunks = p->sppChunks > 0 ? p->sppChunks : srtDefaultSppChunks(p->spp);
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
-  a.shadeMin = envInt("SRT_SHADE_MIN", 32);
+  a.shadeMin = envInt("SRT_SHADE_MIN", 16);
   a.primMin = envInt("SRT_PRIM_MIN", 12);
+  a.hitMin = envInt("SRT_HIT_MIN", 24);
   a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 16));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;

@@ -75,7 +75,7 @@ struct RenderArgs {
   int32_t tileFirst, tileStride, numLocalTiles;
   int32_t sppChunks;
   int32_t numWork;  // numLocalTiles * sppChunks * 64 (one item = one pixel x one sample chunk)
-  int32_t shadeMin, primMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
+  int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t nodeBurst;          // max node visits per scheduling decision
   int32_t* queue;   // persistent-wave work counter (zeroed before launch)
   float4* out;      // [chunk][localTile][64]

@@ -612,20 +612,21 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 //
 // Every lane is an independent persistent worker: it pulls a work item (one pixel x one
 // sample chunk) from a global counter, runs that pixel's samples in index order, writes the
-// partial sum and pulls the next item.  A lane is always in exactly one of three states --
-// at a BVH node, at a primitive, or at a shading point (path vertex / new camera ray / new
-// work item) -- and each trip round the wave's loop executes ONE kind of step for the lanes
+// partial sum and pulls the next item.  A lane is always in exactly one of four states --
+// at a BVH node, at a primitive, at a hit to be shaded (path vertex), or at a path restart (path
+// ended or ray missed: add the sample, new camera ray, possibly a new work item) -- and each trip
+// round the wave's loop executes ONE kind of step for the lanes
 // that are in that state, chosen by ballot counts.  Box tests, primitive tests and shading
 // are therefore each executed by a well-filled wave although the 64 paths are at different
 // depths of different trees (the reference's 1.74 rays/sample x 55 node visits/ray vary by
 // two orders of magnitude from ray to ray).
-enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3 };
+enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3, M_HIT = 4 };
 
 template <bool CLOSEST, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
   // per-thread LDS slots, [slot][thread]: stackDepth+1 traversal slots (one spare for the node step's
-  // unconditional store), then 3*maxBounce attenuation floats
+  // unconditional store), then 3*maxBounce attenuation floats and 3 floats of terminal radiance
   int32_t* stack = lds + threadIdx.x;
   float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 1) * SRT_BLOCK + threadIdx.x);
   const int lane = threadIdx.x & 63;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
 
   // ---- lane state
   int mode = M_SHADE;
-  bool hasRay = false;   // a finished traversal (hitRef, closest) is waiting to be shaded
+  int pend = 0;          // path end waiting to be added at the restart step: 1 = miss (background), 2 = terminal in LDS
   int s = 0, sEnd = 0;   // samples [s, sEnd) of the current work item remain
   int sCount = 0, outIndex = -1;
   int px = 0, py = 0;
@@ -674,17 +675,34 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       if (++w < sc.numWorld) next = sc.world[w];
     }
     cur = next;
-    hasRay = hasRay || (next == SRT_REF_DONE);
-    mode = (next == SRT_REF_DONE) ? M_SHADE : (next >= 0 ? M_NODE : M_PRIM);
+    const bool finished = next == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
+    pend = (finished && missed) ? 1 : pend;
+    mode = finished ? (missed ? M_SHADE : M_HIT) : (next >= 0 ? M_NODE : M_PRIM);
+  };
+  // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
+  auto startTraversal = [&]() {
+    if (COUNT) cRays++;
+    rayA = lenSq(ray.d);  // sphere.h:56
+    rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
+              fastDivOperandOk(ray.o.z, ray.d.z);
+    rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
+    closest = SRT_INF;
+    hitRef = SRT_REF_DONE;
+    sp = 0;
+    w = 0;
+    cur = sc.world[0];
+    mode = cur >= 0 ? M_NODE : M_PRIM;
   };
 
   for (;;) {
     const unsigned long long mN = __ballot(mode == M_NODE), mP = __ballot(mode == M_PRIM),
-                             mS = __ballot(mode == M_SHADE);
-    const int nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS);
-    if ((nN | nP | nS) == 0) break;
+                             mS = __ballot(mode == M_SHADE), mH = __ballot(mode == M_HIT);
+    const int nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nH = __popcll(mH);
+    if ((nN | nP | nS | nH) == 0) break;
     int pick;
-    if (nS >= a.shadeMin || (nN | nP) == 0)
+    if (nH >= a.hitMin || (nN | nP | nS) == 0)
+      pick = M_HIT;
+    else if (nS >= a.shadeMin || (nN | nP) == 0)
       pick = M_SHADE;
     else if (nP >= a.primMin || nN == 0)
       pick = M_PRIM;
@@ -692,9 +710,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       pick = M_NODE;
     pick = __builtin_amdgcn_readfirstlane(pick);
     const unsigned long long pT0 = COUNT ? clock64() : 0;
+    const int pk = pick == M_HIT ? 2 : pick;  // profile slot: hit shading and restarts share the "shade" row
     if (COUNT && pick != M_NODE) {
-      pSteps[pick]++;
-      pLanes[pick] += pick == M_PRIM ? nP : nS;
+      pSteps[pk]++;
+      pLanes[pk] += pick == M_PRIM ? nP : (pick == M_HIT ? nH : nS);
     }
 
     if (pick == M_NODE) {
@@ -744,8 +763,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             cur = SRT_REF_DONE;
             if (++w < sc.numWorld) cur = sc.world[w];
           }
-          hasRay = hasRay || (cur == SRT_REF_DONE);
-          mode = (cur == SRT_REF_DONE) ? M_SHADE : (cur >= 0 ? M_NODE : M_PRIM);
+          const bool finished = cur == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
+          pend = (finished && missed) ? 1 : pend;
+          mode = finished ? (missed ? M_SHADE : M_HIT) : (cur >= 0 ? M_NODE : M_PRIM);
         }
       } while (--budget > 0 && __popcll(__ballot(mode == M_NODE)) >= keep);
     } else if (pick == M_PRIM) {
@@ -776,58 +796,64 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         }
         popNext();
       }
-    } else {
-      // ------------------------------------------------ rayColor (main.cpp:33-52) + pixel loop (main.cpp:200-227)
-      if (mode == M_SHADE) {
-        bool needCamera = !hasRay;
-        if (hasRay) {
-          hasRay = false;
-          V3 terminal;
-          bool done;
-          if (hitRef == SRT_REF_DONE) {
-            terminal = background;  // main.cpp:39-40
-            done = true;
-          } else {
-            Record rec;
-            int pr = ~hitRef;
-            if (pr & 1)
-              sphereRecord(sc, pr >> 1, ray, closest, rec, false);
-            else
-              triRecord(sc, pr >> 1, ray, closest, rec, false);
-            V3 att, emitted;
-            Ray next;
-            uint32_t fetches = 0;
-            if (COUNT && rec.isTri) cShTri++;
-            bool scattered = shade<COUNT>(sc, ray, rec, rng, att, next, emitted, fetches);
-            if (COUNT) cTex += fetches;
-            if (!scattered) {
-              terminal = emitted;  // main.cpp:46-47
-              done = true;
-            } else {
-              // emitted is (0,0,0) for every scattering material (material.h:18-20)
-              attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
-              attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
-              attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
-              ray = next;
-              depth++;
-              done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
-              terminal = mk(0.0f, 0.0f, 0.0f);
-            }
-          }
-          if (done) {
-            // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
-            V3 L = terminal;
-            for (int j = depth - 1; j >= 0; --j) {
-              float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
-                    az = attStack[(3 * j + 2) * SRT_BLOCK];
-              L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
-            }
-            acc = acc + L;  // main.cpp:217
-            s++;
-            needCamera = true;
-          }
+    } else if (pick == M_HIT) {
+      // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
+      if (mode == M_HIT) {
+        Record rec;
+        int pr = ~hitRef;
+        if (pr & 1)
+          sphereRecord(sc, pr >> 1, ray, closest, rec, false);
+        else
+          triRecord(sc, pr >> 1, ray, closest, rec, false);
+        V3 att, emitted;
+        Ray next;
+        uint32_t fetches = 0;
+        if (COUNT && rec.isTri) cShTri++;
+        bool scattered = shade<COUNT>(sc, ray, rec, rng, att, next, emitted, fetches);
+        if (COUNT) cTex += fetches;
+        V3 terminal = emitted;  // main.cpp:46-47
+        bool done = true;
+        if (scattered) {
+          // emitted is (0,0,0) for every scattering material (material.h:18-20)
+          attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
+          attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
+          attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
+          ray = next;
+          depth++;
+          done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
+          terminal = mk(0.0f, 0.0f, 0.0f);
         }
-        if (needCamera && s >= sEnd) {
+        if (done) {
+          // the path ends here: leave its terminal radiance for the restart step
+          attStack[(3 * a.maxBounce + 0) * SRT_BLOCK] = terminal.x;
+          attStack[(3 * a.maxBounce + 1) * SRT_BLOCK] = terminal.y;
+          attStack[(3 * a.maxBounce + 2) * SRT_BLOCK] = terminal.z;
+          pend = 2;
+          mode = M_SHADE;
+        } else {
+          startTraversal();
+        }
+      }
+    } else {
+      // ------------------------------------------------ path restart: miss / path end (main.cpp:39-40,49-51),
+      // pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
+      if (mode == M_SHADE) {
+        if (pend != 0) {
+          V3 L = background;  // main.cpp:39-40
+          if (pend == 2)
+            L = mk(attStack[(3 * a.maxBounce + 0) * SRT_BLOCK], attStack[(3 * a.maxBounce + 1) * SRT_BLOCK],
+                   attStack[(3 * a.maxBounce + 2) * SRT_BLOCK]);
+          pend = 0;
+          // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
+          for (int j = depth - 1; j >= 0; --j) {
+            float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
+                  az = attStack[(3 * j + 2) * SRT_BLOCK];
+            L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
+          }
+          acc = acc + L;  // main.cpp:217
+          s++;
+        }
+        if (s >= sEnd) {
           // work item finished (or none yet): write it, pull the next one with one atomic per wave
           if (outIndex >= 0) a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
           const unsigned long long mF = __ballot(1);
@@ -860,35 +886,19 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             outIndex = (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln;
           }
         }
-        if (mode != M_EXIT) {
-          if (needCamera && s < sEnd) {
-            rng.key(seedMixed, pixel, (uint32_t)s);
-            float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
-            float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
-            cameraRay(a.cam, u, v, rng, ray);
-            depth = 0;
-            needCamera = false;
-            if (COUNT) cSamples++;
-          }
-          if (!needCamera) {
-            // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
-            if (COUNT) cRays++;
-            rayA = lenSq(ray.d);  // sphere.h:56
-            rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
-                      fastDivOperandOk(ray.o.z, ray.d.z);
-            rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
-            closest = SRT_INF;
-            hitRef = SRT_REF_DONE;
-            sp = 0;
-            w = 0;
-            cur = sc.world[0];
-            mode = cur >= 0 ? M_NODE : M_PRIM;
-          }
-          // else: empty item (pixel outside the image): stays in M_SHADE and pulls again
+        if (mode != M_EXIT && s < sEnd) {
+          rng.key(seedMixed, pixel, (uint32_t)s);
+          float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
+          float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
+          cameraRay(a.cam, u, v, rng, ray);
+          depth = 0;
+          if (COUNT) cSamples++;
+          startTraversal();
         }
+        // else: exit, or an empty item (pixel outside the image): stays in M_SHADE and pulls again
       }
     }
-    if (COUNT) pCyc[pick] += clock64() - pT0;
+    if (COUNT) pCyc[pk] += clock64() - pT0;
   }
 
   if (COUNT && a.stats) {

@@ -28,6 +28,9 @@ def test_abi_struct_sizes(abi):
     assert C.sizeof(abi.SrtTextureIn) == 48
     assert C.sizeof(abi.SrtRay) == 36
     assert C.sizeof(abi.SrtHit) == 88
+    assert C.sizeof(abi.SrtWorldItem) == 40
+    assert C.sizeof(abi.SrtRenderParams) == 64
+    assert C.sizeof(abi.SrtStats) == 18 * 8
 
 
 @pytest.mark.parametrize("name", ["spheres", "iron", "masterchief"])

@@ -26,9 +26,11 @@ def main():
     grid = {"chunks": [int(x) for x in os.environ.get("SWEEP_CHUNKS", "8,16,32").split(",")],
             "shade": [int(x) for x in os.environ.get("SWEEP_SHADE", "16,24,32,40").split(",")],
             "prim": [int(x) for x in os.environ.get("SWEEP_PRIM", "12,20,28").split(",")],
-            "burst": [int(x) for x in os.environ.get("SWEEP_BURST", "4").split(",")]}
-    for c, sm, pm, nb in itertools.product(grid["chunks"], grid["shade"], grid["prim"], grid["burst"]):
+            "burst": [int(x) for x in os.environ.get("SWEEP_BURST", "16").split(",")],
+            "hit": [int(x) for x in os.environ.get("SWEEP_HIT", "24").split(",")]}
+    for c, sm, pm, nb, hm in itertools.product(grid["chunks"], grid["shade"], grid["prim"], grid["burst"], grid["hit"]):
         os.environ["SRT_SHADE_MIN"], os.environ["SRT_PRIM_MIN"], os.environ["SRT_NODE_BURST"] = str(sm), str(pm), str(nb)
-        print("chunks %3d shadeMin %2d primMin %2d burst %2d : %8.1f Msamples/s" % (c, sm, pm, nb, run(c)), flush=True)
+        os.environ["SRT_HIT_MIN"] = str(hm)
+        print("chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d : %8.1f Msamples/s" % (c, sm, pm, nb, hm, run(c)), flush=True)
 
 main()

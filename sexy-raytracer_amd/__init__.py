@@ -9,7 +9,7 @@ Layout:
   csrc/      hand-written HIP kernels + the C-ABI library (libsrt_hip.so)
   host/      C++ host mirror of the reference's hittable/material/texture API
   abi.py     ctypes mirror of include/srt_hip.h, SceneBuilder
-  device.py  ctypes binding of libsrt_hip.so (fails loudly when it is missing)
+  hipdev.py  ctypes binding of libsrt_hip.so (fails loudly when it is missing); srt.device() returns it
   scenes.py  the BASELINE.json config scenes
   gltf.py    glTF reader with gltfLoad's semantics (model.h:301-460)
 """
@@ -20,5 +20,7 @@ scenes = _il.import_module(__name__ + ".scenes")
 
 
 def device():
-    """Lazy: loads libsrt_hip.so; raises if the HIP extension is not built."""
-    return _il.import_module(__name__ + ".device")
+    """Lazy: loads libsrt_hip.so (hipdev.py); raises if the HIP extension is not built.
+    (The binding module is not called device.py: importing a submodule of that name would replace
+    this function on the package.)"""
+    return _il.import_module(__name__ + ".hipdev")

@@ -44,6 +44,23 @@ def test_host_bvh_matches_oracle(dev, oracle, srt, name):
     assert 1 <= stack_depth <= depth
 
 
+def test_bvh_topology_fixture(dev, oracle, srt):
+    """tests/golden/bvh_topology.json (tools/make_golden.py): pre-order node
+    arrays of the config scenes, pinned by hash so that neither restatement of bvh.h:55-95 can drift."""
+    import hashlib
+    import json
+    from conftest import GOLD
+    gold = json.load(open(os.path.join(GOLD, "bvh_topology.json")))
+    for name, g in gold.items():
+        sb = srt.scenes.SCENES[name]()
+        nodes, _ = dev.build_bvh_host(sb)
+        onodes, depth = oracle.OracleScene(sb).bvh(0)
+        assert len(nodes) == g["nodes"] and depth == g["depth_root1"]
+        assert hashlib.sha1(nodes.tobytes()).hexdigest() == g["sha1_nodes"]
+        assert hashlib.sha1(onodes.tobytes()).hexdigest() == g["sha1_nodes"]
+        assert [int(nodes[i]["left"]) for i in range(min(4, len(nodes)))] == [n["left"] for n in g["first_nodes"]]
+
+
 def test_host_bvh_soup_and_moving_spheres(dev, oracle, srt):
     sb = srt.scenes.scene_soup(5000, seed=3)
     nodes, _ = dev.build_bvh_host(sb)

@@ -6,6 +6,7 @@
                           outputs the reference ships; statistical parity anchors.
   rng_kat.json            libstdc++ mt19937 known answers.
   trace_<scene>.npz       fixed ray set -> oracle hit records (prim, t bits, ...).
+  bvh_topology.json       pre-order node arrays of the config scenes (count, depth, sha1, first nodes).
   render_<scene>.npz      tiny full renders by the oracle in COUNTER and MT mode
                           (float accumulators + RGBA8).
 """
@@ -98,6 +99,13 @@ def main():
         np.savez_compressed(os.path.join(GOLD, "render_%s.npz" % name), width=W, height=H, spp=spp, max_bounce=mb,
                             seed=7, accum_counter=acc_c, rgba_counter=rgba_c, accum_mt=acc_m, rgba_mt=rgba_m,
                             stats_counter=json.dumps(st_c), stats_mt=json.dumps(st_m))
+        nodes, depth = osc.bvh(0)
+        import hashlib
+        topo = json.load(open(os.path.join(GOLD, "bvh_topology.json"))) if os.path.exists(os.path.join(GOLD, "bvh_topology.json")) else {}
+        topo[name] = {"nodes": len(nodes), "depth_root1": depth, "sha1_nodes": hashlib.sha1(nodes.tobytes()).hexdigest(),
+                      "first_nodes": [{"left": int(n["left"]), "right": int(n["right"]), "bmin": [float(x) for x in n["bmin"]],
+                                       "bmax": [float(x) for x in n["bmax"]]} for n in nodes[:4]]}
+        json.dump(topo, open(os.path.join(GOLD, "bvh_topology.json"), "w"), indent=1)
         print(name, "rays", len(allrays), "hits", int((hits["prim"] >= 0).sum()),
               "faithful!=closest", int((hits["prim"] != closest["prim"]).sum() + ((hits["prim"] == closest["prim"]) & (hits["t"] != closest["t"])).sum()))
 

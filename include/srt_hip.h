@@ -287,6 +287,13 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
  * plain IEEE division on count operand pairs.  HOST pointers. */
 int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
 
+/* Design probe (not part of the render path): throughput of a traversal-only kernel (the render kernel's
+ * node / primitive steps with lanes pulling rays from an array) on a caller-supplied ray set, processed
+ * `reps` times.  Single-root scenes with static spheres.  msOut = kernel time; tOut/refOut (optional, n
+ * entries) = hit distance and device primitive reference per ray. */
+int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut,
+                     int32_t* refOut);
+
 /* Duration of the most recent srtRenderTiles kernel, from HIP events recorded
  * on its stream (synchronises on the stop event). */
 int srtLastKernelMs(SrtContext* ctx, float* ms);

@@ -29,6 +29,9 @@ int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsByte
 int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                    uint8_t* outAxis, int base, int* depthOut);
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
+int srt_launch_travbench(const DevScene* sc, const float4* rays, float2* out, int32_t* queue, int n, int reps, float tMin,
+                         int primMin, int fetchMin, int nodeBurst, unsigned long long* stats, int grid, size_t ldsBytes,
+                         hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
 }
@@ -881,6 +884,58 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
   if (dHits) (void)hipFree(dHits);
   if (dOut) (void)hipFree(dOut);
   return rc;
+}
+
+// design probe: traversal-only throughput on a caller-supplied ray set (single-root scenes, static spheres)
+int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) {
+  if (!ctx || !rays || n < 1 || reps < 1 || !msOut) return 1;
+  if (!ctx->haveScene) return fail(ctx, "travbench: no scene uploaded");
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  std::vector<float4> packed((size_t)n * 2);
+  for (int i = 0; i < n; ++i) {
+    packed[2 * (size_t)i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], rays[i].time);
+    packed[2 * (size_t)i + 1] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], 0.0f);
+  }
+  float4* dRays = nullptr;
+  float2* dOut = nullptr;
+  HIP_OK(ctx, hipMalloc((void**)&dRays, packed.size() * sizeof(float4)));
+  HIP_OK(ctx, hipMalloc((void**)&dOut, (size_t)n * sizeof(float2)));
+  HIP_OK(ctx, hipMemcpy(dRays, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+  const size_t lds = (size_t)(ctx->scene.stackDepth + 1) * 256 * sizeof(int32_t);
+  const int grid = ctx->prop.multiProcessorCount * envInt("SRT_TB_BLOCKS", 8);
+  int rc = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {  // warm-up, then timed
+    HIP_OK(ctx, hipMemset(ctx->dQueue, 0, 2 * sizeof(int32_t)));
+    HIP_OK(ctx, hipMemset(ctx->dStats, 0, 18 * sizeof(unsigned long long)));
+    HIP_OK(ctx, hipEventRecord(ctx->evStart, nullptr));
+    rc = srt_launch_travbench(&ctx->scene, dRays, dOut, ctx->dQueue, n, reps, 0.001f, envInt("SRT_PRIM_MIN", 12),
+                              envInt("SRT_FETCH_MIN", 8), envInt("SRT_NODE_BURST", 16),
+                              envInt("SRT_TB_PROFILE", 0) ? ctx->dStats : nullptr, grid, lds, nullptr);
+    HIP_OK(ctx, hipEventRecord(ctx->evStop, nullptr));
+    HIP_OK(ctx, hipEventSynchronize(ctx->evStop));
+    HIP_OK(ctx, hipEventElapsedTime(msOut, ctx->evStart, ctx->evStop));
+  }
+  if (!rc && tOut && refOut) {
+    std::vector<float2> h(n);
+    HIP_OK(ctx, hipMemcpy(h.data(), dOut, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      tOut[i] = h[i].x;
+      memcpy(&refOut[i], &h[i].y, 4);
+    }
+  }
+  if (envInt("SRT_TB_PROFILE", 0)) {
+    unsigned long long v[9];
+    HIP_OK(ctx, hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost));
+    const char* names[3] = {"node", "prim", "fetch"};
+    for (int k = 0; k < 3; ++k)
+      fprintf(stderr, "travbench %-5s: %12llu executions, mean fill %5.1f lanes, %8.1f clocks/execution, %5.1f%% of step time\n", names[k],
+              v[3 + k], v[3 + k] ? (double)v[6 + k] / v[3 + k] : 0.0, v[3 + k] ? (double)v[k] / v[3 + k] : 0.0,
+              100.0 * v[k] / (double)(v[0] + v[1] + v[2] + 1));
+  }
+  (void)hipFree(dRays);
+  (void)hipFree(dOut);
+  if (rc) return fail(ctx, "travbench launch failed");
+  return 0;
 }
 
 // test entry: the slab test's reciprocal-based division against the plain IEEE division

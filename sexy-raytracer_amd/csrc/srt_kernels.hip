@@ -1043,6 +1043,152 @@ __global__ void srt_scatter_kernel(const ScatterArgs a) {
   o[10] = em.x; o[11] = em.y; o[12] = em.z;
 }
 
+// =================================================================== traversal-only throughput probe
+// Design experiment (srtTraverseBench): the render kernel's node / primitive steps alone, lanes pulling
+// rays from an array with a wave-aggregated counter, results (t, ref) written per ray.  Small register
+// footprint -> up to 8 waves/SIMD.  Answers "how many rays/s would a traversal-only kernel of a
+// wavefront (traverse / shade split) design reach?" before such a design is built.
+struct TravBenchArgs {
+  DevScene scene;
+  const float4* rays;  // 2 x float4 per ray: (o.xyz, time) (d.xyz, -)
+  float2* out;         // (t, ref bits) per ray
+  int32_t* queue;
+  int32_t n, reps;
+  float tMin;
+  int32_t primMin, fetchMin, nodeBurst;
+  unsigned long long* stats;  // 9 slots: cycles[3], executions[3], lanes[3] per step kind (node, prim, fetch)
+};
+
+__global__ __launch_bounds__(SRT_BLOCK, 8) void srt_travbench_kernel(const TravBenchArgs a) {
+  unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
+  extern __shared__ int32_t lds[];
+  int32_t* stack = lds + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const DevScene& sc = a.scene;
+  const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
+  const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
+  const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
+  enum { T_NODE = 0, T_PRIM = 1, T_FETCH = 2, T_EXIT = 3 };
+  int mode = T_FETCH;
+  int rayIdx = -1;
+  long long batchPos = 0, batchEnd = 0;
+  Ray ray;
+  ray.o = ray.d = mk(0, 0, 0);
+  ray.time = 0;
+  int cur = SRT_REF_DONE, sp = 0, hitRef = SRT_REF_DONE;
+  float closest = SRT_INF, rayA = 0;
+  V3 rcpD = mk(0, 0, 0);
+  bool rayFast = false;
+  const long long total = (long long)a.n * a.reps;
+  for (;;) {
+    const int nN = __popcll(__ballot(mode == T_NODE)), nP = __popcll(__ballot(mode == T_PRIM)),
+              nF = __popcll(__ballot(mode == T_FETCH));
+    if ((nN | nP | nF) == 0) break;
+    int pick = (nF >= a.fetchMin || (nN | nP) == 0) ? T_FETCH : ((nP >= a.primMin || nN == 0) ? T_PRIM : T_NODE);
+    pick = __builtin_amdgcn_readfirstlane(pick);
+    const unsigned long long pT0 = a.stats ? clock64() : 0;
+    if (a.stats && pick != T_NODE) {
+      pSteps[pick]++;
+      pLanes[pick] += pick == T_PRIM ? nP : nF;
+    }
+    if (pick == T_NODE) {
+      const int keep = nN - (nN >> 2);
+      int budget = a.nodeBurst;
+      do {
+        if (a.stats) {
+          pSteps[0]++;
+          pLanes[0] += __popcll(__ballot(mode == T_NODE));
+        }
+        if (mode == T_NODE) {
+          float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
+          bool hitBox;
+          if (rayFast) {
+            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
+            hitBox = sure > 0;
+            if (sure == 0) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
+          } else {
+            hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+          }
+          const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+          const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
+          stack[sp * SRT_BLOCK] = right;
+          const bool push = hitBox && right != left, pop = !hitBox && sp > 0, exhausted = !hitBox && sp == 0;
+          sp += (push ? 1 : 0) - (pop ? 1 : 0);
+          sp = min(sp, sc.stackDepth);
+          cur = hitBox ? left : top;
+          if (exhausted) cur = SRT_REF_DONE;
+          mode = cur == SRT_REF_DONE ? T_FETCH : (cur >= 0 ? T_NODE : T_PRIM);
+        }
+      } while (--budget > 0 && __popcll(__ballot(mode == T_NODE)) >= keep);
+    } else if (pick == T_PRIM) {
+      if (mode == T_PRIM) {
+        int pr = ~cur;
+        float t;
+        bool ok;
+        if (pr & 1) {
+          const int off = (pr >> 1) * 48;
+          float4 q0 = bufLoad4(rsSpheres, off);
+          ok = sphereHitV(mk(q0.x, q0.y, q0.z), q0.w, ray, rayA, a.tMin, closest, t);
+        } else {
+          const int off = (pr >> 1) * 48;
+          ok = triHitV<false>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray, a.tMin,
+                              closest, t);
+        }
+        if (ok) {
+          closest = t;
+          hitRef = cur;
+        }
+        const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
+        const bool havePending = sp > 0;
+        sp -= havePending ? 1 : 0;
+        cur = havePending ? top : SRT_REF_DONE;
+        mode = cur == SRT_REF_DONE ? T_FETCH : (cur >= 0 ? T_NODE : T_PRIM);
+      }
+    } else {
+      if (mode == T_FETCH) {
+        if (rayIdx >= 0) a.out[rayIdx] = make_float2(closest, __int_as_float(hitRef));
+        // lanes claim rays in batches of 16 (one global counter saturates near 90 M atomics/s)
+        if (batchPos >= batchEnd) {
+          const unsigned long long mF = __ballot(1);
+          const int leader = __ffsll((long long)mF) - 1;
+          long long base = 0;
+          if (lane == leader) base = (long long)atomicAdd((unsigned long long*)a.queue, (unsigned long long)__popcll(mF) * 16ull);
+          base = __shfl(base, leader);
+          batchPos = base + 16ll * __popcll(mF & ((1ull << lane) - 1ull));
+          batchEnd = batchPos + 16;
+        }
+        const long long idx = batchPos++;
+        if (idx >= total) {
+          mode = T_EXIT;
+          rayIdx = -1;
+        } else {
+          rayIdx = (int)(idx % a.n);
+          float4 r0 = a.rays[2 * (size_t)rayIdx], r1 = a.rays[2 * (size_t)rayIdx + 1];
+          ray.o = mk(r0.x, r0.y, r0.z);
+          ray.time = r0.w;
+          ray.d = mk(r1.x, r1.y, r1.z);
+          rayA = lenSq(ray.d);
+          rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
+                    fastDivOperandOk(ray.o.z, ray.d.z);
+          rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
+          closest = SRT_INF;
+          hitRef = SRT_REF_DONE;
+          sp = 0;
+          cur = sc.world[0];
+          mode = cur >= 0 ? T_NODE : T_PRIM;
+        }
+      }
+    }
+    if (a.stats) pCyc[pick] += clock64() - pT0;
+  }
+  if (a.stats && lane == 0)
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(&a.stats[k], pCyc[k]);
+      atomicAdd(&a.stats[3 + k], pSteps[k]);
+      atomicAdd(&a.stats[6 + k], pLanes[k]);
+    }
+}
+
 // fastDiv vs the compiler's IEEE division on arbitrary operand arrays (srtDivTest)
 __global__ void srt_divtest_kernel(const float* n, const float* d, float* fast, float* slow, int count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1054,6 +1200,14 @@ __global__ void srt_divtest_kernel(const float* n, const float* d, float* fast, 
 
 // =================================================================== launch wrappers (host)
 extern "C" {
+
+int srt_launch_travbench(const DevScene* sc, const float4* rays, float2* out, int32_t* queue, int n, int reps, float tMin,
+                         int primMin, int fetchMin, int nodeBurst, unsigned long long* stats, int grid, size_t ldsBytes,
+                         hipStream_t stream) {
+  TravBenchArgs a{*sc, rays, out, queue, n, reps, tMin, primMin, fetchMin, nodeBurst, stats};
+  hipLaunchKernelGGL(srt_travbench_kernel, dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, a);
+  return (int)hipGetLastError();
+}
 
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream) {
   hipLaunchKernelGGL(srt_divtest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, n, d, fast, slow, count);

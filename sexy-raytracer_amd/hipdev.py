@@ -20,7 +20,7 @@ lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
            "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks",
-           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest", "srtDivTest",
+           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest", "srtDivTest", "srtTraverseBench",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 
 _vp = C.c_void_p
@@ -49,6 +49,7 @@ lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
+lib.srtTraverseBench.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
 lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -180,6 +181,14 @@ class Context:
         fast, slow = np.zeros_like(n), np.zeros_like(n)
         self._check(lib.srtDivTest(self.h, n.ctypes.data, d.ctypes.data, len(n), fast.ctypes.data, slow.ctypes.data))
         return fast, slow
+
+    def traverse_bench(self, rays, reps=1):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        ms = C.c_float(0)
+        t = np.zeros(len(rays), np.float32)
+        ref = np.zeros(len(rays), np.int32)
+        self._check(lib.srtTraverseBench(self.h, rays.ctypes.data, len(rays), reps, C.byref(ms), t.ctypes.data, ref.ctypes.data))
+        return ms.value, t, ref
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

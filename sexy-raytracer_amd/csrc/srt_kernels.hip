@@ -465,8 +465,25 @@ template <bool COUNT>
 __device__ __forceinline__ V3 texValue(const DevScene& sc, int id, float u, float v, V3 p, uint32_t& fetches) {
   const DevTexture& t = sc.textures[id];
   if (t.kind == SRT_TEX_CHECKER) {  // texture.h:42-48
-    float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
-    int child = (sines < 0) ? t.odd : t.even;
+    // Only the sign of sinf(10x)*sinf(10y)*sinf(10z) is used.  sin(a) is negative exactly when
+    // floor(a/pi) is odd; a float is never close enough to a multiple of pi for sinf to lose the sign,
+    // so the three range reductions below replace three sinf calls.  Arguments within 1e-6 of a
+    // multiple of pi (in units of pi), zero and non-finite ones take the reference's expression.
+    const float ax = 10.0f * p.x, ay = 10.0f * p.y, az = 10.0f * p.z;
+    const double qx = (double)ax * 0.31830988618379067, qy = (double)ay * 0.31830988618379067,
+                 qz = (double)az * 0.31830988618379067;
+    const double fx = floor(qx), fy = floor(qy), fz = floor(qz);
+    const double rx = qx - fx, ry = qy - fy, rz = qz - fz;
+    const bool clear = rx > 1e-6 && rx < 1.0 - 1e-6 && ry > 1e-6 && ry < 1.0 - 1e-6 && rz > 1e-6 && rz < 1.0 - 1e-6 &&
+                       fabs(qx) < 1e9 && fabs(qy) < 1e9 && fabs(qz) < 1e9;
+    bool negative;
+    if (clear) {
+      negative = ((((long long)fx) ^ ((long long)fy) ^ ((long long)fz)) & 1) != 0;
+    } else {
+      float sines = sinf(ax) * sinf(ay) * sinf(az);
+      negative = sines < 0;
+    }
+    int child = negative ? t.odd : t.even;
     return texLeaf<COUNT>(sc, child, u, v, fetches) * 255.0f;
   }
   return texLeaf<COUNT>(sc, id, u, v, fetches);

@@ -1,5 +1,5 @@
 """Exploration run on the GPU box: parity numbers + timings printed, nothing asserted.
-Usage: python tools/gpu_explore.py [scene] [W H spp bounces]"""
+Usage: python tests/gpu_explore.py [scene] [W H spp bounces]"""
 import importlib
 import os
 import sys

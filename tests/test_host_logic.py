@@ -45,7 +45,7 @@ def test_host_bvh_matches_oracle(dev, oracle, srt, name):
 
 
 def test_bvh_topology_fixture(dev, oracle, srt):
-    """tests/golden/bvh_topology.json (tools/make_golden.py): pre-order node
+    """tests/golden/bvh_topology.json (tests/make_golden.py): pre-order node
     arrays of the config scenes, pinned by hash so that neither restatement of bvh.h:55-95 can drift."""
     import hashlib
     import json

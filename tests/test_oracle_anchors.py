@@ -1,7 +1,7 @@
 """Pins the CPU oracle (oracle/oracle.cpp) against everything the reference offers for this
 path: libstdc++ RNG known answers, the BVH statistics and traversal counters recorded in
 SURVEY.md A.5, and region means of the two published renders (tests/golden/published_regions.json,
-made by tools/make_golden.py from /root/reference/images).  The reference ships no tests."""
+made by tests/make_golden.py from /root/reference/images).  The reference ships no tests."""
 import json
 import os
 

@@ -898,43 +898,48 @@ int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t rep
   }
   float4* dRays = nullptr;
   float2* dOut = nullptr;
-  HIP_OK(ctx, hipMalloc((void**)&dRays, packed.size() * sizeof(float4)));
-  HIP_OK(ctx, hipMalloc((void**)&dOut, (size_t)n * sizeof(float2)));
-  HIP_OK(ctx, hipMemcpy(dRays, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+  const bool profile = envInt("SRT_TB_PROFILE", 0) != 0;
   const size_t lds = (size_t)(ctx->scene.stackDepth + 1) * 256 * sizeof(int32_t);
   const int grid = ctx->prop.multiProcessorCount * envInt("SRT_TB_BLOCKS", 8);
-  int rc = 0;
-  for (int pass = 0; pass < 2 && !rc; ++pass) {  // warm-up, then timed
-    HIP_OK(ctx, hipMemset(ctx->dQueue, 0, 2 * sizeof(int32_t)));
-    HIP_OK(ctx, hipMemset(ctx->dStats, 0, 18 * sizeof(unsigned long long)));
-    HIP_OK(ctx, hipEventRecord(ctx->evStart, nullptr));
-    rc = srt_launch_travbench(&ctx->scene, dRays, dOut, ctx->dQueue, n, reps, 0.001f, envInt("SRT_PRIM_MIN", 12),
-                              envInt("SRT_FETCH_MIN", 8), envInt("SRT_NODE_BURST", 16),
-                              envInt("SRT_TB_PROFILE", 0) ? ctx->dStats : nullptr, grid, lds, nullptr);
-    HIP_OK(ctx, hipEventRecord(ctx->evStop, nullptr));
-    HIP_OK(ctx, hipEventSynchronize(ctx->evStop));
-    HIP_OK(ctx, hipEventElapsedTime(msOut, ctx->evStart, ctx->evStop));
-  }
-  if (!rc && tOut && refOut) {
-    std::vector<float2> h(n);
-    HIP_OK(ctx, hipMemcpy(h.data(), dOut, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) {
-      tOut[i] = h[i].x;
-      memcpy(&refOut[i], &h[i].y, 4);
+  hipError_t e = hipSuccess;
+  do {
+    if ((e = hipMalloc((void**)&dRays, packed.size() * sizeof(float4))) != hipSuccess) break;
+    if ((e = hipMalloc((void**)&dOut, (size_t)n * sizeof(float2))) != hipSuccess) break;
+    if ((e = hipMemcpy(dRays, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) break;
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {  // warm-up, then timed
+      if ((e = hipMemset(ctx->dQueue, 0, 2 * sizeof(int32_t))) != hipSuccess) break;
+      if ((e = hipMemset(ctx->dStats, 0, 18 * sizeof(unsigned long long))) != hipSuccess) break;
+      if ((e = hipEventRecord(ctx->evStart, nullptr)) != hipSuccess) break;
+      e = (hipError_t)srt_launch_travbench(&ctx->scene, dRays, dOut, ctx->dQueue, n, reps, 0.001f, envInt("SRT_PRIM_MIN", 12),
+                                           envInt("SRT_FETCH_MIN", 32), envInt("SRT_NODE_BURST", 16),
+                                           profile ? ctx->dStats : nullptr, grid, lds, nullptr);
+      if (e != hipSuccess) break;
+      if ((e = hipEventRecord(ctx->evStop, nullptr)) != hipSuccess) break;
+      if ((e = hipEventSynchronize(ctx->evStop)) != hipSuccess) break;
+      e = hipEventElapsedTime(msOut, ctx->evStart, ctx->evStop);
     }
-  }
-  if (envInt("SRT_TB_PROFILE", 0)) {
-    unsigned long long v[9];
-    HIP_OK(ctx, hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost));
-    const char* names[3] = {"node", "prim", "fetch"};
-    for (int k = 0; k < 3; ++k)
-      fprintf(stderr, "travbench %-5s: %12llu executions, mean fill %5.1f lanes, %8.1f clocks/execution, %5.1f%% of step time\n", names[k],
-              v[3 + k], v[3 + k] ? (double)v[6 + k] / v[3 + k] : 0.0, v[3 + k] ? (double)v[k] / v[3 + k] : 0.0,
-              100.0 * v[k] / (double)(v[0] + v[1] + v[2] + 1));
-  }
-  (void)hipFree(dRays);
-  (void)hipFree(dOut);
-  if (rc) return fail(ctx, "travbench launch failed");
+    if (e != hipSuccess) break;
+    if (tOut && refOut) {
+      std::vector<float2> h(n);
+      if ((e = hipMemcpy(h.data(), dOut, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost)) != hipSuccess) break;
+      for (int i = 0; i < n; ++i) {
+        tOut[i] = h[i].x;
+        memcpy(&refOut[i], &h[i].y, 4);
+      }
+    }
+    if (profile) {
+      unsigned long long v[9];
+      if ((e = hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost)) != hipSuccess) break;
+      const char* names[3] = {"node", "prim", "fetch"};
+      for (int k = 0; k < 3; ++k)
+        fprintf(stderr, "travbench %-5s: %12llu executions, mean fill %5.1f lanes, %8.1f clocks/execution, %5.1f%% of step time\n",
+                names[k], v[3 + k], v[3 + k] ? (double)v[6 + k] / v[3 + k] : 0.0, v[3 + k] ? (double)v[k] / v[3 + k] : 0.0,
+                100.0 * v[k] / (double)(v[0] + v[1] + v[2] + 1));
+    }
+  } while (0);
+  if (dRays) (void)hipFree(dRays);
+  if (dOut) (void)hipFree(dOut);
+  if (e != hipSuccess) return fail(ctx, "travbench failed: %s", hipGetErrorString(e));
   return 0;
 }
 

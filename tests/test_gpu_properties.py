@@ -352,3 +352,20 @@ def test_headline_frame_against_published_render(ctx, abi, srt, camera):
         assert np.abs(mean - pub["regions"][name]["mean_rgb"]).max() <= t, (name, mean, pub["regions"][name]["mean_rgb"])
     black = int((rgba[..., :3].sum(-1) == 0).sum())
     assert black < 20 * max(1, pub["black_pixels"]), black
+
+
+def test_240p_frame_against_published_render(ctx, abi, srt, camera):
+    """The other published render, images/test-1kx240p.png (426x240, ~1000 spp)."""
+    import json
+    import os
+    from conftest import GOLD
+    pub = json.load(open(os.path.join(GOLD, "published_regions.json")))["test-1kx240p.png"]
+    ctx.upload_scene(srt.scenes.scene_masterchief())
+    ctx.set_camera(camera)
+    _, rgba = ctx.render_image(abi.default_render_params(426, 240, 1000, 4, seed=1, spp_chunks=0), want_accum=False)
+    img = rgba[..., :3].astype(np.float64)
+    tol = {"sky": 0.01, "far_ground": 2.5, "metal_sphere": 2.5, "ground": 3.0, "chief": 4.0}
+    for name, t in tol.items():
+        y0, y1, x0, x1 = pub["regions"][name]["rows_cols"]
+        mean = img[y0:y1, x0:x1].mean((0, 1))
+        assert np.abs(mean - pub["regions"][name]["mean_rgb"]).max() <= t, (name, mean, pub["regions"][name]["mean_rgb"])

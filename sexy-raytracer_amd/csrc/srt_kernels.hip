@@ -6,25 +6,22 @@
 // material::scatter bodies (material.h:91-97,108-126,144-150,156-245), pbr.h:58-81,
 // texture::value (texture.h:26-28,42-48,129-148) and writeColorTarget (color.h:25-41).
 //
-// Execution model (CDNA4):
-//   * one wavefront (64 lanes) owns one 8x8 pixel tile; lane = pixel.  Waves are
-//     persistent and pull (tile, sample-chunk) work items from an atomic counter,
-//     so long tiles (ground, mesh) and short tiles (sky) balance across the 256 CUs.
-//   * a lane runs its pixel's samples in index order and adds them in that order
-//     (main.cpp:204-218), so accumulators are reproducible bit for bit and
-//     independent of tiling / GPU count.  When a lane's path ends it immediately
-//     generates its next camera ray ("path regeneration"), so every traversal
-//     step has all unfinished lanes active regardless of bounce depth.
-//   * bounce recursion is a loop; the per-bounce attenuations sit in a small
-//     per-lane LDS stack and are folded innermost-first at path end, which
-//     reproduces the recursion's rounding (E + A*(E' + A'*(...))) exactly.
-//   * BVH traversal is a per-lane DFS in the reference's fixed left-then-right
-//     order with the pending right children on a per-lane LDS stack laid out
-//     [slot][thread] (bank = thread: conflict-free), "while-while" shaped so
-//     box tests and primitive tests are each executed by converged lanes.
+// Execution model (CDNA4), details at srt_render_kernel:
+//   * every lane is a persistent worker: it pulls a work item (one pixel x one chunk of its
+//     samples; 64 consecutive items = one 8x8 tile) from an atomic counter, runs the chunk's samples in
+//     index order and adds them in that order (main.cpp:204-218), writes one float4 partial sum and pulls
+//     the next item.  Accumulators are reproducible bit for bit and independent of tiling / GPU count.
+//   * a wave-level scheduler runs ONE kind of step per trip -- BVH node visits, primitive tests, hit
+//     shading or path restarts -- for the lanes that are in that state, picked from ballot counts, so the
+//     64 lanes stay busy although their paths are at different depths of different subtrees.
+//   * bounce recursion is a loop; the per-bounce attenuations sit in a small per-lane LDS stack and are
+//     folded innermost-first at path end, which reproduces the recursion's rounding
+//     (E + A*(E' + A'*(...))) exactly.
+//   * BVH traversal is a per-lane DFS in the reference's fixed left-then-right order with the pending
+//     right children on a per-lane LDS stack laid out [slot][thread] (bank = thread: conflict-free).
 //   * RNG: PCG32 keyed by (seed, pixel, sample) per lane.
-//   * all arithmetic keeps the reference's operation order; built with
-//     -ffp-contract=off; divisions and sqrt are IEEE (hipcc default).
+//   * all arithmetic keeps the reference's operation order; built with -ffp-contract=off; divisions and
+//     sqrt are IEEE (hipcc default); the slab test's divisions go through a certified exact shortcut.
 // No MFMA: there is no dense contraction on this path.
 
 #include <hip/hip_runtime.h>

@@ -251,9 +251,10 @@ int srtBuildBvh(const SrtSceneDesc* scene, int32_t item, SrtBvhNode* out, int32_
 int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count);
 int srtGetBvhDepth(SrtContext* ctx, int32_t* depth);
 
-/* Tiles: the image is cut into 8x8-pixel tiles, row-major tile ids; one
- * wavefront renders one tile (lane = pixel).  srtNumLocalTiles gives the
- * (rank-padded) tile count of one rank: ceil(numTiles / tileStride). */
+/* Tiles: the image is cut into 8x8-pixel tiles, row-major tile ids.  Tiles are the unit of
+ * the multi-GPU split (rank r of N renders tiles r, r+N, ...) and of the output layout
+ * ([tile][64 pixels] float4); inside the kernel lanes pull (pixel, sample chunk) work items.
+ * srtNumLocalTiles gives the (rank-padded) tile count of one rank: ceil(numTiles / tileStride). */
 int32_t srtNumTiles(int32_t imageWidth, int32_t imageHeight);
 int32_t srtNumLocalTiles(int32_t imageWidth, int32_t imageHeight, int32_t tileStride);
 

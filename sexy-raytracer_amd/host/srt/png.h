@@ -1,6 +1,6 @@
 // png.h -- PNG decode / encode for the scene-build path, replacing the stb calls the reference
 // makes (stbi_load at texture.h:62,115; stbi_write_png at main.cpp:237).  zlib does the inflate /
-// deflate.  Decodes 8- and 16-bit grey, grey+alpha, RGB, RGBA and palette PNGs (non-interlaced) and
+// deflate.  Decodes 1- to 16-bit grey, grey+alpha, RGB, RGBA and palette PNGs (non-interlaced) and
 // converts to the requested component count with stb_image's rules (luma = (77r+150g+29b)>>8,
 // 16-bit -> high byte); for the 8-bit RGB / L files this path loads, the bytes are the file's own.
 #ifndef SRT_HOST_PNG_H
@@ -45,10 +45,15 @@ inline uint8_t* srtPngLoad(const char* filename, int* w, int* h, int* comp, int 
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + (size_t)len;
   }
-  if (!width || !height || interlace || (depth != 8 && depth != 16 && ctype != 3) || (ctype == 3 && depth != 8)) return nullptr;
+  const bool lowDepth = depth == 1 || depth == 2 || depth == 4;  // allowed for grey and palette only
+  if (!width || !height || interlace || !(depth == 8 || depth == 16 || lowDepth) || (lowDepth && ctype != 0 && ctype != 3) ||
+      (ctype == 3 && depth == 16))
+    return nullptr;
   int fileComp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!fileComp) return nullptr;
-  const size_t bps = depth / 8, stride = (size_t)width * fileComp * bps, bpp = fileComp * bps;
+  const size_t bps = depth >= 8 ? depth / 8 : 1;
+  const size_t stride = lowDepth ? ((size_t)width * depth + 7) / 8 : (size_t)width * fileComp * bps;
+  const size_t bpp = lowDepth ? 1 : fileComp * bps;
   std::vector<uint8_t> raw((stride + 1) * height);
   uLongf rawLen = raw.size();
   if (uncompress(raw.data(), &rawLen, idat.data(), idat.size()) != Z_OK || rawLen != raw.size()) return nullptr;
@@ -76,6 +81,17 @@ inline uint8_t* srtPngLoad(const char* filename, int* w, int* h, int* comp, int 
       }
       out[x] = (uint8_t)v;
     }
+  }
+  if (lowDepth) {  // unpack 1/2/4-bit samples (MSB first); grey is scaled to 8 bits, palette indices stay
+    std::vector<uint8_t> wide((size_t)width * height);
+    const int mask = (1 << depth) - 1, scale = ctype == 0 ? 255 / mask : 1;
+    for (uint32_t y = 0; y < height; ++y)
+      for (uint32_t x = 0; x < width; ++x) {
+        const size_t bit = (size_t)x * depth;
+        const int v = (img[y * stride + (bit >> 3)] >> (8 - depth - (bit & 7))) & mask;
+        wide[(size_t)y * width + x] = (uint8_t)(v * scale);
+      }
+    img.swap(wide);
   }
   // to 8-bit RGBA-ish working pixels
   int srcComp = fileComp;

@@ -744,6 +744,16 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.tileStride = p->tileStride;
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
   a.sppChunks = p->sppChunks > 0 ? p->sppChunks : srtDefaultSppChunks(p->spp);
+  {
+    // work items and output slots are indexed with 32-bit integers in the kernel
+    const int64_t perChunk = (int64_t)a.numLocalTiles * SRT_TILE_PIXELS;
+    const int64_t maxChunks = (int64_t)0x7fffffff / std::max<int64_t>(perChunk, 1);
+    if (maxChunks < 1) return fail(ctx, "render: image too large (%d local tiles)", a.numLocalTiles);
+    if (a.sppChunks > maxChunks) {
+      if (p->sppChunks > 0) return fail(ctx, "render: sppChunks %d x %d tiles exceeds 2^31 work items", p->sppChunks, a.numLocalTiles);
+      a.sppChunks = (int32_t)maxChunks;
+    }
+  }
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.shadeMin = envInt("SRT_SHADE_MIN", 16);
   a.primMin = envInt("SRT_PRIM_MIN", 12);

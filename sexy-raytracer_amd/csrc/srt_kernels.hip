@@ -743,14 +743,11 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         if (mode == M_NODE) {
           float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
           if (COUNT) cNodes++;
-          bool hitBox;
-          if (rayFast) {
-            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
-            hitBox = sure > 0;
-            if (sure == 0) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);  // rare: exact quotients
-          } else {
-            hitBox = boxHit(n0, n1, ray, a.tMin, closest);
-          }
+          // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
+          // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
+          const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
+          bool hitBox = sure > 0;
+          if (!rayFast || sure == 0) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
           if (COUNT && hitBox) cBox++;
           // descend left and leave right pending, or take the next pending reference (selects, see popNext)
           int left = __float_as_int(n0.w), right = __float_as_int(n1.w);

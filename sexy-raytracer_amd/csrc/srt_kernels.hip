@@ -650,6 +650,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
   const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
+  const bool singleRoot = sc.numWorld == 1;
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
   // scheduler profile (COUNT variant only; wave-uniform)
@@ -684,7 +685,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     const bool havePending = sp > 0;
     sp -= havePending ? 1 : 0;
     int next = top;
-    if (!havePending) {  // once per ray: next root of the world list, or done
+    if (singleRoot) {
+      next = havePending ? top : SRT_REF_DONE;
+    } else if (!havePending) {  // once per ray: next root of the world list, or done
       next = SRT_REF_DONE;
       if (++w < sc.numWorld) next = sc.world[w];
     }
@@ -770,7 +773,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           sp += (push ? 1 : 0) - (pop ? 1 : 0);
           sp = min(sp, sc.stackDepth);  // capacity is guaranteed at upload; never index LDS beyond it regardless
           cur = hitBox ? left : top;
-          if (exhausted) {  // once per ray
+          if (singleRoot) {  // wave-uniform: the usual world is one bvhNode (main.cpp:146)
+            cur = exhausted ? SRT_REF_DONE : cur;
+          } else if (exhausted) {  // once per ray: next root of the world list
             cur = SRT_REF_DONE;
             if (++w < sc.numWorld) cur = sc.world[w];
           }

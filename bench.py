@@ -156,7 +156,7 @@ def main():
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
     chunks = max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else dev.default_spp_chunks(spp)
     params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
-                                       spp_chunks=chunks)
+                                       spp_chunks=chunks if args.spp_chunks > 0 else 0)  # 0 = library plan
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms = []
 

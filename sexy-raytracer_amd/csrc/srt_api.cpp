@@ -285,7 +285,8 @@ int envInt(const char* name, int dflt) {
 }
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
-  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce + 3) * 256 * sizeof(int32_t);
+  // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
+  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 
 }  // namespace
@@ -360,7 +361,7 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   ctx->device = deviceOrdinal;
   HIP_OK(ctx, hipSetDevice(deviceOrdinal));
   HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
-  HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, 64));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, SRT_MAX_QUEUES * 16 * sizeof(int32_t)));
   HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 18 * sizeof(unsigned long long)));
   HIP_OK(ctx, hipEventCreate(&ctx->evStart));
   HIP_OK(ctx, hipEventCreate(&ctx->evStop));
@@ -733,6 +734,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.imageWidth = p->imageWidth;
   a.imageHeight = p->imageHeight;
   a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
+  a.tileBlock = std::max(1, envInt("SRT_TILE_BLOCK", SRT_TILE_BLOCK));
   a.numTiles = srtNumTiles(p->imageWidth, p->imageHeight);
   a.spp = p->spp;
   a.maxBounce = p->maxBounce;
@@ -745,8 +747,21 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, p->tileStride);
   a.sppChunks = p->sppChunks > 0 ? p->sppChunks : srtDefaultSppChunks(p->spp);
   {
-    // work items and output slots are indexed with 32-bit integers in the kernel
-    const int64_t perChunk = (int64_t)a.numLocalTiles * SRT_TILE_PIXELS;
+    // work queues (srt_render_kernel): units of >= 8 consecutive local tiles, about a dozen units per queue,
+    // at most 64 queues.  Measured on the 720p headline frame (ms per launch, 1 rank / one of 8 ranks):
+    // 1 queue 1916 / 253, 16 queues x 8 tiles 1818 / 238, 64 x 8: 1767 / 255, 64 x 16: 1744 / -.
+    const auto pow2Floor = [](int v) { int r = 1; while (2 * r <= v) r *= 2; return r; };
+    int unit = 8;
+    const int unitsAt8 = (a.numLocalTiles + 7) / 8;
+    if (unitsAt8 >= 2 * 12 * SRT_MAX_QUEUES) unit = 8 * pow2Floor(unitsAt8 / (12 * SRT_MAX_QUEUES));
+    a.unitTiles = std::min(1024, std::max(1, envInt("SRT_UNIT_TILES", unit)));
+    const int units = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
+    a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, envInt("SRT_QUEUES", pow2Floor(std::max(1, units / 12)))));
+  }
+  {
+    // work items and output slots are indexed with 32-bit integers in the kernel (queue counters run over
+    // whole units, so count the padding of the last unit of every queue too)
+    const int64_t perChunk = ((int64_t)a.numLocalTiles + (int64_t)a.unitTiles * a.numQueues) * SRT_TILE_PIXELS;
     const int64_t maxChunks = (int64_t)0x7fffffff / std::max<int64_t>(perChunk, 1);
     if (maxChunks < 1) return fail(ctx, "render: image too large (%d local tiles)", a.numLocalTiles);
     if (a.sppChunks > maxChunks) {
@@ -755,6 +770,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
     }
   }
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
+  a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
   a.shadeMin = envInt("SRT_SHADE_MIN", 16);
   a.primMin = envInt("SRT_PRIM_MIN", 12);
   a.hitMin = envInt("SRT_HIT_MIN", 24);
@@ -781,7 +797,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
-  HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t), stream));
+  HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 18 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
   int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
@@ -805,6 +821,7 @@ int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGath
   a.imageWidth = p->imageWidth;
   a.imageHeight = p->imageHeight;
   a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
+  a.tileBlock = std::max(1, envInt("SRT_TILE_BLOCK", SRT_TILE_BLOCK));
   a.tileStride = p->tileStride < 1 ? 1 : p->tileStride;
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, a.tileStride);
   a.spp = p->spp;

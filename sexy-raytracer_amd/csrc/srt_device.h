@@ -16,6 +16,7 @@
 //   ref <  0          primitive: r = ~ref, (r & 1) = 1 sphere / 0 triangle, r >> 1 = index
 //   SRT_REF_DONE      traversal sentinel (never a valid primitive)
 #define SRT_REF_DONE ((int32_t)0x80000000)
+#define SRT_MAX_QUEUES 64
 
 struct DevMaterial {  // 48 B
   int32_t type;
@@ -73,11 +74,14 @@ struct RenderArgs {
   float background[3];
   float tMin;
   int32_t tileFirst, tileStride, numLocalTiles;
+  int32_t tileBlock;   // tile order: row-major inside tileBlock x tileBlock blocks of tiles (srtTileFromOrder)
+  int32_t numQueues;   // work counters; a wave starts on queue blockIdx % numQueues
+  int32_t unitTiles, numUnits;  // queue q owns units q, q+numQueues, ... of unitTiles consecutive local tiles
   int32_t sppChunks;
   int32_t numWork;  // numLocalTiles * sppChunks * 64 (one item = one pixel x one sample chunk)
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t nodeBurst;          // max node visits per scheduling decision
-  int32_t* queue;   // persistent-wave work counter (zeroed before launch)
+  int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // [chunk][localTile][64]
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr
 };
@@ -93,9 +97,39 @@ struct ResolveArgs {
   const float4* gathered;  // [rank][localTile][64]
   int32_t imageWidth, imageHeight, tilesX;
   int32_t tileStride, numLocalTiles;
+  int32_t tileBlock;
   int32_t spp;
   uint8_t* rgba;      // may be null
   float4* accumImage;  // may be null
 };
+
+
+// ---- tile order.  Tiles are numbered along a blocked curve, not row-major: the image is cut into
+// B x B blocks of tiles (edge blocks smaller), blocks row-major, tiles row-major inside a block with row
+// iy rotated by iy.  Work is issued in this order (so the tiles in flight at any time form a compact 2-D
+// patch and the rays in flight stay coherent) and ranks take every tileStride-th position of it (the
+// rotation keeps a rank's tiles from lining up in columns).  B = 1 is plain row-major.
+#if defined(__HIPCC__)
+#define SRT_HD __host__ __device__
+#else
+#define SRT_HD
+#endif
+SRT_HD inline void srtTileFromOrder(int i, int tilesX, int tilesY, int B, int& tx, int& ty) {
+  const int by = i / (B * tilesX), r = i - by * B * tilesX;
+  const int bh = (tilesY - by * B) < B ? (tilesY - by * B) : B;
+  const int bx = r / (B * bh), r2 = r - bx * B * bh;
+  const int bw = (tilesX - bx * B) < B ? (tilesX - bx * B) : B;
+  const int iy = r2 / bw, ixr = r2 - iy * bw;
+  int ix = ixr - iy % bw;
+  ix = ix < 0 ? ix + bw : ix;
+  tx = bx * B + ix;
+  ty = by * B + iy;
+}
+SRT_HD inline int srtOrderFromTile(int tx, int ty, int tilesX, int tilesY, int B) {
+  const int by = ty / B, iy = ty - by * B, bx = tx / B, ix = tx - bx * B;
+  const int bh = (tilesY - by * B) < B ? (tilesY - by * B) : B;
+  const int bw = (tilesX - bx * B) < B ? (tilesX - bx * B) : B;
+  return by * B * tilesX + bx * B * bh + iy * bw + (ix + iy) % bw;
+}
 
 #endif

@@ -657,6 +657,20 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
   const unsigned long long pStart = COUNT ? clock64() : 0;
 
+  // ---- work queues.  The local tiles (in tile order) are cut into units of unitTiles tiles, dealt
+  // round-robin to numQueues queues with one counter each, so that the waves of a workgroup (home queue
+  // blockIdx % numQueues) stay on a few neighbouring tiles: their rays touch the same part of the scene,
+  // and since workgroups are dealt to the XCDs round-robin (XCD = blockIdx % 8) each L2 sees a few patches
+  // of the image instead of all tiles in flight.
+  // A wave that finds its queue drained moves to the queue with the most items left (steals), preferring
+  // the queues of its own XCD; when none has any left its idle lanes leave.  The wave's current queue
+  // lives in one LDS word (-1: everything drained) so that every lane sees it whichever lanes pulled last.
+  int32_t* waveQueue = lds + (a.scene.stackDepth + 1 + 3 * a.maxBounce + 3) * SRT_BLOCK + (threadIdx.x >> 6);
+  const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
+  if (lane == 0) *waveQueue = qHome;
+  const int unitItems = a.unitTiles * a.sppChunks * SRT_TILE_PIXELS;
+  auto queueEnd = [&](int q) { return (q < a.numUnits ? (a.numUnits - q + a.numQueues - 1) / a.numQueues : 0) * unitItems; };
+
   // ---- lane state
   int mode = M_SHADE;
   int pend = 0;          // path end waiting to be added at the restart step: 1 = miss (background), 2 = terminal in LDS
@@ -875,18 +889,54 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           const unsigned long long mF = __ballot(1);
           const int leader = __ffsll((long long)mF) - 1;
           int base = 0;
-          if (lane == leader) base = atomicAdd(a.queue, __popcll(mF));
-          base = __shfl(base, leader);
-          const int idx = base + __popcll(mF & ((1ull << lane) - 1ull));
-          if (idx >= a.numWork) {
+          const int q = *waveQueue;  // wave-uniform
+          bool gotItem = false;
+          int idx = 0;
+          if (q >= 0) {
+            // queue q holds the units q, q + Q, q + 2Q, ... of the unit order (a unit = unitTiles consecutive
+            // local tiles, all their chunks): every queue walks the whole image
+            if (lane == leader) base = atomicAdd(a.queue + 16 * q, __popcll(mF));
+            base = __shfl(base, leader);
+            idx = base + __popcll(mF & ((1ull << lane) - 1ull));
+            const int qEnd = queueEnd(q);
+            gotItem = idx < qEnd;
+            if (base + __popcll(mF) > qEnd) {
+              // drained (wave-uniform): the leader looks at every queue's counter and the wave moves to the
+              // fullest one, own XCD first.  Counters only grow, so "nothing left anywhere" is final.
+              int nq = -1;
+              if (lane == leader) {
+                int bestLeft = 0;
+                bool bestOwn = false;
+                for (int k = 0; k < a.numQueues; ++k) {
+                  const int left = queueEnd(k) - __hip_atomic_load(a.queue + 16 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  const bool own = ((k ^ qHome) & 7) == 0;
+                  if (left > 0 && ((own && !bestOwn) || (own == bestOwn && left > bestLeft))) {
+                    bestLeft = left;
+                    bestOwn = own;
+                    nq = k;
+                  }
+                }
+                *waveQueue = nq;
+              }
+              nq = __shfl(nq, leader);
+              if (!gotItem && nq < 0) mode = M_EXIT;
+            }
+          } else {
             mode = M_EXIT;
-            outIndex = -1;
+          }
+          outIndex = -1;
+          if (!gotItem) {
+            // nothing from this queue: an empty item; pulls again from the new queue on the next restart step
+            s = sEnd = 0;
           } else {
             // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk
-            const int group = idx >> 6, ln = idx & 63;
-            const int localTile = group / a.sppChunks, chunk = group - localTile * a.sppChunks;
+            const int u = idx / unitItems, inUnit = idx - u * unitItems;
+            const int group = inUnit >> 6, ln = inUnit & 63;
+            const int tileInUnit = group / a.sppChunks, chunk = group - tileInUnit * a.sppChunks;
+            const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
             const int tile = a.tileFirst + localTile * a.tileStride;
-            const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+            int tx, ty;
+            srtTileFromOrder(tile < a.numTiles ? tile : 0, a.tilesX, a.numTiles / a.tilesX, a.tileBlock, tx, ty);
             px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
             py = ty * SRT_TILE_H + (ln >> 3);
             pixel = (uint32_t)(py * a.imageWidth + px);
@@ -895,11 +945,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             const int s1 = a.sampleFirst + (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
             sCount = s1 - s0;
             // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
-            const bool valid = tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && a.maxBounce > 0;
+            const bool valid = localTile < a.numLocalTiles && tile < a.numTiles && px < a.imageWidth && py < a.imageHeight &&
+                               a.maxBounce > 0;
             s = s0;
             sEnd = valid ? s1 : s0;
             acc = mk(0.0f, 0.0f, 0.0f);
-            outIndex = (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln;
+            outIndex = localTile < a.numLocalTiles ? (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln : -1;
           }
         }
         if (mode != M_EXIT && s < sEnd) {
@@ -955,7 +1006,7 @@ __global__ void srt_resolve_kernel(const ResolveArgs a) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.imageWidth * a.imageHeight) return;
   int x = idx % a.imageWidth, y = idx / a.imageWidth;
-  int tile = (y / SRT_TILE_H) * a.tilesX + (x / SRT_TILE_W);
+  int tile = srtOrderFromTile(x / SRT_TILE_W, y / SRT_TILE_H, a.tilesX, (a.imageHeight + SRT_TILE_H - 1) / SRT_TILE_H, a.tileBlock);
   int lane = (y % SRT_TILE_H) * SRT_TILE_W + (x % SRT_TILE_W);
   int rank = tile % a.tileStride, local = tile / a.tileStride;
   float4 v = a.gathered[((size_t)rank * a.numLocalTiles + local) * SRT_TILE_PIXELS + lane];

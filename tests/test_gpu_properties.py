@@ -64,7 +64,31 @@ def test_sample_sum_linearity(ctx, abi, srt, camera):
         ch, _ = ctx.render_image(p)
         assert (ch[..., 3] == 32).all()
         np.testing.assert_allclose(ch[..., :3], seq[..., :3], rtol=2e-5, atol=1e-6)
-    p.sppChunks = 1
+    # the library's own plan (0): equal body chunks plus halving tail chunks, every sample exactly once,
+    # and the same per-pixel summation order for any tile split
+    for spp in (64, 100, 333):
+        p = abi.default_render_params(426, 240, spp, 8, seed=8)
+        seq, _ = ctx.render_image(p)
+        p.sppChunks = 0
+        auto, _ = ctx.render_image(p)
+        assert (auto[..., 3] == spp).all()
+        np.testing.assert_allclose(auto[..., :3], seq[..., :3], rtol=2e-5, atol=1e-6)
+    import torch
+    from importlib import import_module
+    tiles = import_module("sexy-raytracer_amd.tiles")
+    dev = srt.device()
+    nloc = dev.num_local_tiles(426, 240, 3)
+    parts = []
+    for r in range(3):
+        buf = torch.zeros((nloc, 64, 4), dtype=torch.float32, device="cuda")
+        ctx.render_tiles(abi.default_render_params(426, 240, 333, 8, seed=8, tile_first=r, tile_stride=3, spp_chunks=0),
+                         buf.data_ptr())
+        torch.cuda.synchronize()
+        parts.append(buf.cpu().numpy())
+    joined = np.ascontiguousarray(tiles.untile(np.stack(parts), 426, 240, 3), dtype=np.float32)
+    assert np.array_equal(joined.view(np.uint32), np.ascontiguousarray(auto).view(np.uint32))  # bit patterns: NaN-safe
+    p = abi.default_render_params(426, 240, 32, 8, seed=8)
+    seq, _ = ctx.render_image(p)
     # different seed -> different image, same statistics
     p.seed = 9
     other, _ = ctx.render_image(p)

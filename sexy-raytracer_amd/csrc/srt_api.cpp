@@ -756,7 +756,12 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
     if (unitsAt8 >= 2 * 12 * SRT_MAX_QUEUES) unit = 8 * pow2Floor(unitsAt8 / (12 * SRT_MAX_QUEUES));
     a.unitTiles = std::min(1024, std::max(1, envInt("SRT_UNIT_TILES", unit)));
     const int units = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
-    a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, envInt("SRT_QUEUES", pow2Floor(std::max(1, units / 12)))));
+    // ... and only while every wave still gets a few dozen groups: with few groups per wave (16 spp on a
+    // 10 M-triangle soup: 14 400 groups for 5 120 waves) one counter balances better than stealing does.
+    const int64_t groups = (int64_t)a.numLocalTiles * a.sppChunks, waves = (int64_t)ctx->prop.multiProcessorCount * 20;
+    const int byUnits = pow2Floor(std::max(1, units / 12));
+    const int byGroups = pow2Floor((int)std::max<int64_t>(1, std::min<int64_t>(SRT_MAX_QUEUES, groups / (2 * waves))));
+    a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, envInt("SRT_QUEUES", std::min(byUnits, byGroups))));
   }
   {
     // work items and output slots are indexed with 32-bit integers in the kernel (queue counters run over

@@ -29,10 +29,11 @@ def main():
         local = torch.zeros((nloc, 64, 4), dtype=torch.float32, device="cuda")
         ms = []
         for r in range(n):
-            p = abi.default_render_params(W, H, spp, mb, seed=1, tile_first=r, tile_stride=n, spp_chunks=0)
+            p = abi.default_render_params(W, H, spp, mb, seed=1, tile_first=r, tile_stride=n, spp_chunks=int(os.environ.get("CHUNKS", "0")))
             best = 1e9
             for _ in range(2):
-                ctx.render_tiles(p, local.data_ptr(), None)
+                for _ in range(int(os.environ.get("BACK2BACK", "1"))):  # >1: time a launch queued behind another
+                    ctx.render_tiles(p, local.data_ptr(), None)
                 best = min(best, ctx.last_kernel_ms())
             ms.append(round(best, 3))
         print(json.dumps({"unit_tiles": os.environ.get("SRT_UNIT_TILES", "default"), "queues": os.environ.get("SRT_QUEUES", "default"), "tile_block": os.environ.get("SRT_TILE_BLOCK", "default"), "ranks": n, "frame": [W, H, spp], "kernel_ms": ms, "max_ms": max(ms),

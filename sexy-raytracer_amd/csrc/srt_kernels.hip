@@ -625,8 +625,8 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 // main.cpp:200-227 for the tiles of this rank.
 //
 // Every lane is an independent persistent worker: it pulls a work item (one pixel x one
-// sample chunk) from a global counter, runs that pixel's samples in index order, writes the
-// partial sum and pulls the next item.  A lane is always in exactly one of four states --
+// sample chunk) from its wave's current work queue (see "work queues" below), runs that pixel's samples
+// in index order, writes the partial sum and pulls the next item.  A lane is always in exactly one of four states --
 // at a BVH node, at a primitive, at a hit to be shaded (path vertex), or at a path restart (path
 // ended or ray missed: add the sample, new camera ray, possibly a new work item) -- and each trip
 // round the wave's loop executes ONE kind of step for the lanes

@@ -36,8 +36,10 @@ enum { SRT_TEX_SOLID = 0, SRT_TEX_CHECKER = 1, SRT_TEX_IMAGE = 2 };
 enum { SRT_WORLD_PRIM = 0, SRT_WORLD_BVH = 1 };
 /* who builds an SRT_WORLD_BVH item's tree when the caller supplies none:
  * REFERENCE = bvh.h:55-95 on the host (the tree FAITHFUL traversal semantics are defined on);
- * LBVH = a linear BVH built on the device, for SRT_TRAVERSE_CLOSEST rendering of large scenes. */
-enum { SRT_BUILDER_REFERENCE = 0, SRT_BUILDER_LBVH = 1 };
+ * LBVH = a linear BVH built on the device (Morton order + Karras' hierarchy), PLOC = parallel
+ * locally-ordered clustering on the device (surface-area driven, tighter trees, a few times the
+ * LBVH's build time): both for SRT_TRAVERSE_CLOSEST rendering of large scenes. */
+enum { SRT_BUILDER_REFERENCE = 0, SRT_BUILDER_LBVH = 1, SRT_BUILDER_PLOC = 2 };
 /* traversal semantics: FAITHFUL = bvh.h:97-105 order with triangle::hit's
  * missing tMax test (model.h:128); CLOSEST adds the t < closest test. */
 enum { SRT_TRAVERSE_FAITHFUL = 0, SRT_TRAVERSE_CLOSEST = 1 };

@@ -11,7 +11,7 @@ SRT_MAT_PBR, SRT_MAT_METAL, SRT_MAT_DIELECTRIC, SRT_MAT_LIGHT = 0, 1, 2, 3
 SRT_TEX_SOLID, SRT_TEX_CHECKER, SRT_TEX_IMAGE = 0, 1, 2
 SRT_WORLD_PRIM, SRT_WORLD_BVH = 0, 1
 SRT_TRAVERSE_FAITHFUL, SRT_TRAVERSE_CLOSEST = 0, 1
-SRT_BUILDER_REFERENCE, SRT_BUILDER_LBVH = 0, 1
+SRT_BUILDER_REFERENCE, SRT_BUILDER_LBVH, SRT_BUILDER_PLOC = 0, 1, 2
 SRT_TILE_W = SRT_TILE_H = 8
 SRT_TILE_PIXELS = 64
 SRT_NO_HIT = -1

@@ -28,6 +28,8 @@ int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                    uint8_t* outAxis, int base, int* depthOut);
+int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
+                   uint8_t* outAxis, int base, int radius, int* depthOut);
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
 int srt_launch_travbench(const DevScene* sc, const float4* rays, float2* out, int32_t* queue, int n, int reps, float tMin,
                          int primMin, int fetchMin, int nodeBurst, unsigned long long* stats, int grid, size_t ldsBytes,
@@ -500,7 +502,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
       world.push_back(devRef(~it.first));
       continue;
     }
-    if (!it.nodes && it.builder == SRT_BUILDER_LBVH) {
+    if (!it.nodes && (it.builder == SRT_BUILDER_LBVH || it.builder == SRT_BUILDER_PLOC)) {
       // device build (srt_lbvh.hip) after the primitive arrays are uploaded: reserve the node slots
       int32_t base = (int32_t)(nodes.size() / 2), cnt = std::max(it.count - 1, 1);
       nodes.resize(nodes.size() + 2 * (size_t)cnt, make_float4(0, 0, 0, 0));
@@ -609,7 +611,13 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     HIP_OK(ctx, hipMalloc((void**)&dRefs, refs.size() * sizeof(int32_t)));
     hipError_t ce = hipMemcpy(dRefs, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     int depth = 0;
-    int rc = ce != hipSuccess ? (int)ce : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis), dt.base, &depth);
+    int rc = (int)ce;
+    if (ce == hipSuccess)
+      rc = it.builder == SRT_BUILDER_PLOC
+               ? srt_ploc_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
+                                dt.base, envInt("SRT_PLOC_RADIUS", 16), &depth)
+               : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
+                                dt.base, &depth);
     (void)hipFree(dRefs);
     if (rc) return fail(ctx, "device BVH build of world item %d failed: %s", w, hipGetErrorString((hipError_t)rc));
     stackDepth = std::max(stackDepth, depth);

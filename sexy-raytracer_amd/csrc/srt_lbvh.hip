@@ -10,7 +10,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstring>
+#include <utility>
+
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "srt_device.h"
 
@@ -261,4 +266,198 @@ extern "C" int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, f
   rc = (int)e;
   (void)hipFree(pool);
   return rc;
+}
+
+// =================================================================== PLOC (SRT_BUILDER_PLOC)
+// Parallel locally-ordered clustering (Meister & Bittner 2018): the primitives, in Morton order, start as
+// one cluster each; every round each cluster looks `radius` places left and right for the neighbour whose
+// union with it has the smallest surface area, mutual nearest neighbours merge into a node, and the array
+// is compacted in order.  It is an agglomerative build that follows the surface-area heuristic locally,
+// so its trees are markedly tighter than the linear BVH's (which only looks at key prefixes), for a build
+// that is still a few dozen short kernels.  Nodes are numbered from the top down in creation order
+// reversed (the last merge = the root gets index 0), so children always have larger indices than parents.
+namespace {
+
+struct PlocCluster {
+  float4 mn;  // xyz, w = reference (node index or primitive ref) as int bits
+  float4 mx;  // xyz, w = depth of the subtree as int bits
+};
+
+__device__ __forceinline__ float unionArea(const float4& amn, const float4& amx, const float4& bmn, const float4& bmx) {
+  const float dx = fmaxf(amx.x, bmx.x) - fminf(amn.x, bmn.x), dy = fmaxf(amx.y, bmx.y) - fminf(amn.y, bmn.y),
+              dz = fmaxf(amx.z, bmx.z) - fminf(amn.z, bmn.z);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+#define PLOC_BLOCK 256
+#define PLOC_MAX_RADIUS 32
+
+// initial clusters: the primitives in Morton order
+__global__ void plocInit(const int* sortedVals, const int32_t* refs, const float4* boxMin, const float4* boxMax, int n,
+                         PlocCluster* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = sortedVals[i];
+  float4 a = boxMin[p], b = boxMax[p];
+  a.w = __int_as_float(refs[p]);
+  b.w = __int_as_float(1);
+  out[i].mn = a;
+  out[i].mx = b;
+}
+
+// nearest neighbour (smallest union area; ties to the lower position) within `radius` places
+__global__ __launch_bounds__(PLOC_BLOCK) void plocNearest(const PlocCluster* c, int m, int radius, int* nn) {
+  __shared__ float4 sMn[PLOC_BLOCK + 2 * PLOC_MAX_RADIUS], sMx[PLOC_BLOCK + 2 * PLOC_MAX_RADIUS];
+  const int first = blockIdx.x * PLOC_BLOCK - radius;
+  for (int k = threadIdx.x; k < PLOC_BLOCK + 2 * radius; k += PLOC_BLOCK) {
+    const int g = first + k;
+    if (g >= 0 && g < m) {
+      sMn[k] = c[g].mn;
+      sMx[k] = c[g].mx;
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
+  if (i >= m) return;
+  const float4 mn = sMn[threadIdx.x + radius], mx = sMx[threadIdx.x + radius];
+  float best = 3.0e38f;
+  int bestJ = -1;
+  const int lo = max(0, i - radius), hi = min(m - 1, i + radius);
+  for (int j = lo; j <= hi; ++j) {
+    if (j == i) continue;
+    const float a = unionArea(mn, mx, sMn[j - first], sMx[j - first]);
+    if (a < best) {
+      best = a;
+      bestJ = j;
+    }
+  }
+  nn[i] = bestJ;  // -1 only when m == 1
+}
+
+// flags for the in-order compaction: high word = the cluster survives (it is not the right-hand partner of
+// a merge), low word = it is the left-hand partner (one new node)
+__global__ void plocDecide(const int* nn, int m, unsigned long long* flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  const bool mutual = j >= 0 && nn[j] == i;
+  const bool leader = mutual && i < j, absorbed = mutual && i > j;
+  flags[i] = ((unsigned long long)(absorbed ? 0 : 1) << 32) | (unsigned long long)(leader ? 1 : 0);
+}
+
+// emit this round's nodes and the next round's cluster array
+__global__ void plocMerge(const PlocCluster* c, const int* nn, const unsigned long long* flags, const unsigned long long* scanned,
+                          int m, int n, int nodesBefore, int base, float4* outNodes, uint8_t* outAxis, PlocCluster* next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const unsigned long long f = flags[i], sc = scanned[i];
+  if (!(f >> 32)) return;  // absorbed by its partner
+  const int pos = (int)(sc >> 32);
+  PlocCluster me = c[i];
+  if (f & 1ull) {
+    const PlocCluster other = c[nn[i]];
+    // node index: creation order reversed, so that the last node made (the root) is 0
+    const int node = (n - 2) - (nodesBefore + (int)(sc & 0xffffffffull));
+    // left child = lower centroid along the axis where the two centroids differ most (near-child-first
+    // traversal reads the axis; 3 = no usable axis)
+    const float cx = (other.mn.x + other.mx.x) - (me.mn.x + me.mx.x), cy = (other.mn.y + other.mx.y) - (me.mn.y + me.mx.y),
+                cz = (other.mn.z + other.mx.z) - (me.mn.z + me.mx.z);
+    int axis = fabsf(cx) >= fabsf(cy) ? (fabsf(cx) >= fabsf(cz) ? 0 : 2) : (fabsf(cy) >= fabsf(cz) ? 1 : 2);
+    const float d = axis == 0 ? cx : (axis == 1 ? cy : cz);
+    const bool meFirst = d >= 0.0f;
+    if (d == 0.0f) axis = 3;
+    const float4 mn = make_float4(fminf(me.mn.x, other.mn.x), fminf(me.mn.y, other.mn.y), fminf(me.mn.z, other.mn.z), 0.0f);
+    const float4 mx = make_float4(fmaxf(me.mx.x, other.mx.x), fmaxf(me.mx.y, other.mx.y), fmaxf(me.mx.z, other.mx.z), 0.0f);
+    const float4 l = meFirst ? me.mn : other.mn, r = meFirst ? other.mn : me.mn;
+    outNodes[2 * (size_t)(base + node) + 0] = make_float4(mn.x, mn.y, mn.z, l.w);
+    outNodes[2 * (size_t)(base + node) + 1] = make_float4(mx.x, mx.y, mx.z, r.w);
+    outAxis[base + node] = (uint8_t)axis;
+    const int depth = max(__float_as_int(me.mx.w), __float_as_int(other.mx.w)) + 1;
+    me.mn = make_float4(mn.x, mn.y, mn.z, __int_as_float(base + node));
+    me.mx = make_float4(mx.x, mx.y, mx.z, __int_as_float(depth));
+  }
+  next[pos] = me;
+}
+
+}  // namespace
+
+// Same contract as srt_lbvh_build.  radius: clusters examined on either side (1..32).
+extern "C" int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
+                              uint8_t* outAxis, int base, int radius, int* depthOut) {
+  if (n < 1) return (int)hipErrorInvalidValue;
+  if (n == 1) {
+    hipLaunchKernelGGL(lbvhSingle, dim3(1), dim3(1), 0, nullptr, *sc, dRefs, time0, time1, outNodes, base);
+    *depthOut = 1;
+    return (int)hipDeviceSynchronize();
+  }
+  radius = radius < 1 ? 1 : (radius > PLOC_MAX_RADIUS ? PLOC_MAX_RADIUS : radius);
+  const size_t N = (size_t)n;
+  char* pool = nullptr;
+  size_t sortBytes = 0, scanBytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                           (int*)nullptr, (int*)nullptr, N, 0, 64, nullptr);
+  if (e != hipSuccess) return (int)e;
+  e = rocprim::exclusive_scan(nullptr, scanBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, N,
+                              rocprim::plus<unsigned long long>(), nullptr);
+  if (e != hipSuccess) return (int)e;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+  const size_t oBoxMin = take(N * 16), oBoxMax = take(N * 16), oKeys = take(N * 8), oKeys2 = take(N * 8), oVals = take(N * 4),
+               oVals2 = take(N * 4), oBounds = take(64), oClA = take(N * sizeof(PlocCluster)), oClB = take(N * sizeof(PlocCluster)),
+               oNn = take(N * 4), oFlags = take(N * 8), oScan = take(N * 8), oTemp = take(std::max(sortBytes, scanBytes));
+  e = hipMalloc((void**)&pool, off);
+  if (e != hipSuccess) return (int)e;
+  auto P = [&](size_t o) { return pool + o; };
+  const int initBounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  do {
+    if ((e = hipMemcpy(P(oBounds), initBounds, sizeof initBounds, hipMemcpyHostToDevice)) != hipSuccess) break;
+    const int B = PLOC_BLOCK, G = (n + B - 1) / B;
+    hipLaunchKernelGGL(lbvhPrimBoxes, dim3(G), dim3(B), 0, nullptr, *sc, dRefs, n, time0, time1, (float4*)P(oBoxMin),
+                       (float4*)P(oBoxMax), (int*)P(oBounds));
+    hipLaunchKernelGGL(lbvhMorton, dim3(G), dim3(B), 0, nullptr, (const float4*)P(oBoxMin), (const float4*)P(oBoxMax), n,
+                       (const int*)P(oBounds), (unsigned long long*)P(oKeys), (int*)P(oVals));
+    e = rocprim::radix_sort_pairs(P(oTemp), sortBytes, (unsigned long long*)P(oKeys), (unsigned long long*)P(oKeys2),
+                                  (int*)P(oVals), (int*)P(oVals2), N, 0, 64, nullptr);
+    if (e != hipSuccess) break;
+    PlocCluster *cur = (PlocCluster*)P(oClA), *nxt = (PlocCluster*)P(oClB);
+    hipLaunchKernelGGL(plocInit, dim3(G), dim3(B), 0, nullptr, (const int*)P(oVals2), dRefs, (const float4*)P(oBoxMin),
+                       (const float4*)P(oBoxMax), n, cur);
+    int m = n, nodes = 0;
+    // every round merges at least the globally closest mutual pair, so m strictly decreases
+    for (int round = 0; m > 1 && round < 4 * 64 + n; ++round) {
+      const int g = (m + B - 1) / B;
+      hipLaunchKernelGGL(plocNearest, dim3(g), dim3(B), 0, nullptr, cur, m, radius, (int*)P(oNn));
+      hipLaunchKernelGGL(plocDecide, dim3(g), dim3(B), 0, nullptr, (const int*)P(oNn), m, (unsigned long long*)P(oFlags));
+      size_t sb = scanBytes;
+      e = rocprim::exclusive_scan(P(oTemp), sb, (unsigned long long*)P(oFlags), (unsigned long long*)P(oScan), 0ull, (size_t)m,
+                                  rocprim::plus<unsigned long long>(), nullptr);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(plocMerge, dim3(g), dim3(B), 0, nullptr, cur, (const int*)P(oNn), (const unsigned long long*)P(oFlags),
+                         (const unsigned long long*)P(oScan), m, n, nodes, base, outNodes, outAxis, nxt);
+      unsigned long long lastScan = 0, lastFlag = 0;
+      if ((e = hipMemcpy(&lastScan, P(oScan) + (size_t)(m - 1) * 8, 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+      if ((e = hipMemcpy(&lastFlag, P(oFlags) + (size_t)(m - 1) * 8, 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+      const unsigned long long total = lastScan + lastFlag;
+      const int merged = (int)(total & 0xffffffffull), kept = (int)(total >> 32);
+      if (merged < 1 || kept != m - merged) {
+        e = hipErrorUnknown;  // cannot happen: the closest pair is always mutual
+        break;
+      }
+      nodes += merged;
+      m = kept;
+      std::swap(cur, nxt);
+    }
+    if (e != hipSuccess) break;
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if (m != 1 || nodes != n - 1) {
+      e = hipErrorUnknown;
+      break;
+    }
+    PlocCluster root;
+    if ((e = hipMemcpy(&root, cur, sizeof root, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    memcpy(depthOut, &root.mx.w, 4);
+  } while (0);
+  (void)hipFree(pool);
+  return (int)e;
 }

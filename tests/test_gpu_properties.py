@@ -294,12 +294,14 @@ def _tree_checks(nodes, num_prims):
     return True
 
 
-def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera):
-    """the device-built linear BVH.  The closest hit does not depend on the tree, so
-    CLOSEST traversal of the device tree must reproduce the oracle's brute-force closest hit bit for
-    bit, and CLOSEST renders through the device tree and through the reference tree must agree."""
+@pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
+def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera, builder):
+    """the device-built trees (linear BVH; PLOC).  The closest hit does not depend on the
+    tree, so CLOSEST traversal of the device tree must reproduce the oracle's brute-force closest hit bit
+    for bit, and CLOSEST renders through the device tree and through the reference tree must agree."""
     n = 30000
-    sb = srt.scenes.scene_soup(n, seed=5, builder=abi.SRT_BUILDER_LBVH)
+    builder = getattr(abi, "SRT_BUILDER_" + builder)
+    sb = srt.scenes.scene_soup(n, seed=5, builder=builder)
     ctx.upload_scene(sb)
     ctx.set_camera(camera)
     nodes = ctx.bvh(0)
@@ -310,6 +312,11 @@ def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera):
         m = c >= 0
         assert (nodes["bmin"][m] <= nodes["bmin"][c[m]]).all() and (nodes["bmax"][m] >= nodes["bmax"][c[m]]).all()
     assert 15 <= ctx.bvh_depth() <= 64
+    if builder == abi.SRT_BUILDER_PLOC:
+        # children are numbered after their parents (creation order reversed)
+        for child in ("left", "right"):
+            c = nodes[child]
+            assert (c[c >= 0] > np.nonzero(c >= 0)[0]).all()
     rng = np.random.default_rng(9)
     rays = np.zeros(40000, abi.RAY_DTYPE)
     rays["o"] = (0.0, 3.0, 5.0)
@@ -329,7 +336,8 @@ def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera):
     assert same.mean() > 0.999
 
 
-def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera):
+@pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
+def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera, builder):
     for count in (1, 2, 3, 37):
         sb = abi.SceneBuilder()
         m = sb.metal((0.7, 0.6, 0.5), 0.1)
@@ -337,7 +345,7 @@ def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera):
         for _ in range(count):
             c = rng.uniform(-3, 3, 3) + np.array([0, 3, -1])
             sb.add_sphere(tuple(c), 0.5, m, center1=tuple(c + rng.uniform(-0.4, 0.4, 3)), time0=0.0, time1=1.0)
-        sb.world_bvh(0, None, 0.0, 1.0, builder=abi.SRT_BUILDER_LBVH)
+        sb.world_bvh(0, None, 0.0, 1.0, builder=getattr(abi, "SRT_BUILDER_" + builder))
         ctx.upload_scene(sb)
         ctx.set_camera(camera)
         assert _tree_checks(ctx.bvh(0), count)

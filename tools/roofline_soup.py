@@ -12,13 +12,14 @@ from bench import algorithmic_bytes
 
 n = int(sys.argv[1])
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-# optional 3rd argument "lbvh": device-built tree + closest-hit traversal (not the parity path)
-lbvh = len(sys.argv) > 3 and sys.argv[3] == "lbvh"
+# optional 3rd argument "lbvh" / "ploc": device-built tree + closest-hit traversal (not the parity path)
+lbvh = len(sys.argv) > 3 and sys.argv[3] in ("lbvh", "ploc")
+ploc = len(sys.argv) > 3 and sys.argv[3] == "ploc"
 ref_closest = len(sys.argv) > 3 and sys.argv[3] == "closest"  # reference tree, closest-hit (ordered) traversal
 W, H, mb = 1280, 720, 4
 t = time.time()
 sb = srt.scenes.scene_soup(n, seed=7, extent=6.0, size=max(0.01, 0.08 * (100000.0 / n) ** (1.0 / 3.0)),
-                           builder=abi.SRT_BUILDER_LBVH if lbvh else abi.SRT_BUILDER_REFERENCE)
+                           builder=abi.SRT_BUILDER_PLOC if ploc else (abi.SRT_BUILDER_LBVH if lbvh else abi.SRT_BUILDER_REFERENCE))
 trav = abi.SRT_TRAVERSE_CLOSEST if (lbvh or ref_closest) else abi.SRT_TRAVERSE_FAITHFUL
 ctx = dev.Context(0)
 ctx.upload_scene(sb)
@@ -37,7 +38,7 @@ for _ in range(3):
     best = min(best, ctx.last_kernel_ms())
 ms = best
 samples = W * H * spp
-print(json.dumps({"tree": "device LBVH + closest hit" if lbvh else ("reference bvh.h + closest hit" if ref_closest else "reference bvh.h + faithful"), "triangles": n, "nodes_MB": round((2 * n) * 32 / 1e6, 1), "tri_records_MB": round(n * 112 / 1e6, 1),
+print(json.dumps({"tree": "device PLOC + closest hit" if ploc else "device LBVH + closest hit" if lbvh else ("reference bvh.h + closest hit" if ref_closest else "reference bvh.h + faithful"), "triangles": n, "nodes_MB": round((2 * n) * 32 / 1e6, 1), "tri_records_MB": round(n * 112 / 1e6, 1),
                   "bvh_depth": ctx.bvh_depth(), "build_upload_s": round(build_s, 2), "spp": spp,
                   "Msamples_per_s": round(samples / ms / 1e3, 2), "kernel_ms": round(ms, 3),
                   "rays_per_sample": round(st["rays"] / st["samples"], 3),

@@ -615,7 +615,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     if (ce == hipSuccess)
       rc = it.builder == SRT_BUILDER_PLOC
                ? srt_ploc_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
-                                dt.base, envInt("SRT_PLOC_RADIUS", 16), &depth)
+                                dt.base, envInt("SRT_PLOC_RADIUS", 64), &depth)
                : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
                                 dt.base, &depth);
     (void)hipFree(dRefs);

@@ -290,7 +290,7 @@ __device__ __forceinline__ float unionArea(const float4& amn, const float4& amx,
 }
 
 #define PLOC_BLOCK 256
-#define PLOC_MAX_RADIUS 32
+#define PLOC_MAX_RADIUS 128
 
 // initial clusters: the primitives in Morton order
 __global__ void plocInit(const int* sortedVals, const int32_t* refs, const float4* boxMin, const float4* boxMax, int n,
@@ -381,7 +381,7 @@ __global__ void plocMerge(const PlocCluster* c, const int* nn, const unsigned lo
 
 }  // namespace
 
-// Same contract as srt_lbvh_build.  radius: clusters examined on either side (1..32).
+// Same contract as srt_lbvh_build.  radius: clusters examined on either side (1..128).
 extern "C" int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                               uint8_t* outAxis, int base, int radius, int* depthOut) {
   if (n < 1) return (int)hipErrorInvalidValue;

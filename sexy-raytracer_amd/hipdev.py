@@ -114,7 +114,8 @@ class Context:
         self._scene_keep = None
 
     def close(self):
-        if getattr(self, "h", None):
+        # `lib` is already gone when a context is collected at interpreter shutdown
+        if getattr(self, "h", None) and lib is not None:
             lib.srtDestroy(self.h)
             self.h = None
 

@@ -288,7 +288,7 @@ int envInt(const char* name, int dflt) {
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
   // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
-  return (size_t)(ctx->scene.stackDepth + 1 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
+  return (size_t)(ctx->scene.stackDepth + 2 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 
 }  // namespace

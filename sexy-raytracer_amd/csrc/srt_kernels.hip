@@ -639,10 +639,13 @@ enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3, M_HIT = 4 };
 template <bool CLOSEST, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
-  // per-thread LDS slots, [slot][thread]: stackDepth+1 traversal slots (one spare for the node step's
-  // unconditional store), then 3*maxBounce attenuation floats and 3 floats of terminal radiance
-  int32_t* stack = lds + threadIdx.x;
-  float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 1) * SRT_BLOCK + threadIdx.x);
+  // per-thread LDS slots, [slot][thread]: stackDepth+2 traversal slots (slot 0 holds a sentinel, the last
+  // one is a spare for the node step's unconditional store), then 3*maxBounce attenuation floats and 3
+  // floats of terminal radiance
+  int32_t* const stackBase = lds + threadIdx.x;
+  int32_t* const stackTop = stackBase + a.scene.stackDepth * SRT_BLOCK;  // highest slot that may be live
+  *stackBase = SRT_REF_DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
+  float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * SRT_BLOCK + threadIdx.x);
   const int lane = threadIdx.x & 63;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // A wave that finds its queue drained moves to the queue with the most items left (steals), preferring
   // the queues of its own XCD; when none has any left its idle lanes leave.  The wave's current queue
   // lives in one LDS word (-1: everything drained) so that every lane sees it whichever lanes pulled last.
-  int32_t* waveQueue = lds + (a.scene.stackDepth + 1 + 3 * a.maxBounce + 3) * SRT_BLOCK + (threadIdx.x >> 6);
+  int32_t* waveQueue = lds + (a.scene.stackDepth + 2 + 3 * a.maxBounce + 3) * SRT_BLOCK + (threadIdx.x >> 6);
   const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
   if (lane == 0) *waveQueue = qHome;
   const int unitItems = a.unitTiles * a.sppChunks * SRT_TILE_PIXELS;
@@ -686,7 +689,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   rng.state = 0;
   int depth = 0;
   // traversal state (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
-  int cur = SRT_REF_DONE, sp = 0, w = 0, hitRef = SRT_REF_DONE;
+  int cur = SRT_REF_DONE, w = 0, hitRef = SRT_REF_DONE;
+  int32_t* sptr = stackBase;  // top of this lane's stack of pending references (slot 0 = sentinel)
   float closest = SRT_INF, rayA = 0.0f;
   V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
   bool rayFast = false;
@@ -695,15 +699,11 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // Written with selects rather than nested branches: every divergent `if` costs the wave half a
   // dozen scalar exec-mask instructions, and the scalar unit is shared by the CU's four SIMDs.
   auto popNext = [&]() {
-    const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
-    const bool havePending = sp > 0;
-    sp -= havePending ? 1 : 0;
-    int next = top;
-    if (singleRoot) {
-      next = havePending ? top : SRT_REF_DONE;
-    } else if (!havePending) {  // once per ray: next root of the world list, or done
-      next = SRT_REF_DONE;
-      if (++w < sc.numWorld) next = sc.world[w];
+    int next = *sptr;  // the sentinel when nothing is pending
+    sptr -= SRT_BLOCK;
+    if (!singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+      next = sc.world[w];
+      sptr = stackBase;
     }
     cur = next;
     const bool finished = next == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
     closest = SRT_INF;
     hitRef = SRT_REF_DONE;
-    sp = 0;
+    sptr = stackBase;
     w = 0;
     cur = sc.world[0];
     mode = cur >= 0 ? M_NODE : M_PRIM;
@@ -779,19 +779,17 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
               right = tmp;
             }
           }
-          const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
-          stack[sp * SRT_BLOCK] = right;  // slot sp is free; it only becomes live if sp is bumped below
-          const bool push = hitBox && right != left;
-          const bool pop = !hitBox && sp > 0;
-          const bool exhausted = !hitBox && sp == 0;
-          sp += (push ? 1 : 0) - (pop ? 1 : 0);
-          sp = min(sp, sc.stackDepth);  // capacity is guaranteed at upload; never index LDS beyond it regardless
+          const int top = *sptr;     // pending reference, or the sentinel
+          sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
+          // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
+          // miss: take the pending reference
+          int32_t* const up = right != left ? sptr + SRT_BLOCK : sptr;
+          sptr = hitBox ? up : sptr - SRT_BLOCK;
+          sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
           cur = hitBox ? left : top;
-          if (singleRoot) {  // wave-uniform: the usual world is one bvhNode (main.cpp:146)
-            cur = exhausted ? SRT_REF_DONE : cur;
-          } else if (exhausted) {  // once per ray: next root of the world list
-            cur = SRT_REF_DONE;
-            if (++w < sc.numWorld) cur = sc.world[w];
+          if (!singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+            cur = sc.world[w];
+            sptr = stackBase;
           }
           const bool finished = cur == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
           pend = (finished && missed) ? 1 : pend;

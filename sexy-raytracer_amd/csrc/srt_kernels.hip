@@ -675,7 +675,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   auto queueEnd = [&](int q) { return (q < a.numUnits ? (a.numUnits - q + a.numQueues - 1) / a.numQueues : 0) * unitItems; };
 
   // ---- lane state
-  int mode = M_SHADE;
+  // A lane's state is read off its traversal registers: at a node (cur >= 0), at a primitive (cur < 0 but
+  // not DONE), traversal finished with a hit to shade (cur == DONE, hitRef set), or waiting for a restart
+  // (both DONE).  Nothing is recomputed per node visit to keep track of it.
+  bool alive = true;
   int pend = 0;          // path end waiting to be added at the restart step: 1 = miss (background), 2 = terminal in LDS
   int s = 0, sEnd = 0;   // samples [s, sEnd) of the current work item remain
   int sCount = 0, outIndex = -1;
@@ -691,6 +694,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // traversal state (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
   int cur = SRT_REF_DONE, w = 0, hitRef = SRT_REF_DONE;
   int32_t* sptr = stackBase;  // top of this lane's stack of pending references (slot 0 = sentinel)
+  auto atNode = [&]() { return cur >= 0; };
+  auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)SRT_REF_DONE; };
+  auto atHit = [&]() { return cur == SRT_REF_DONE && hitRef != SRT_REF_DONE; };
+  auto atRestart = [&]() { return cur == SRT_REF_DONE && hitRef == SRT_REF_DONE && alive; };
   float closest = SRT_INF, rayA = 0.0f;
   V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
   bool rayFast = false;
@@ -706,9 +713,6 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       sptr = stackBase;
     }
     cur = next;
-    const bool finished = next == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
-    pend = (finished && missed) ? 1 : pend;
-    mode = finished ? (missed ? M_SHADE : M_HIT) : (next >= 0 ? M_NODE : M_PRIM);
   };
   // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
   auto startTraversal = [&]() {
@@ -722,12 +726,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     sptr = stackBase;
     w = 0;
     cur = sc.world[0];
-    mode = cur >= 0 ? M_NODE : M_PRIM;
+    pend = 1;  // a miss unless a hit-shading step says otherwise
   };
 
   for (;;) {
-    const unsigned long long mN = __ballot(mode == M_NODE), mP = __ballot(mode == M_PRIM),
-                             mS = __ballot(mode == M_SHADE), mH = __ballot(mode == M_HIT);
+    const unsigned long long mN = __ballot(atNode()), mP = __ballot(atPrim()), mS = __ballot(atRestart()),
+                             mH = __ballot(atHit());
     const int nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nH = __popcll(mH);
     if ((nN | nP | nS | nH) == 0) break;
     int pick;
@@ -755,9 +759,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       do {
         if (COUNT) {
           pSteps[M_NODE]++;
-          pLanes[M_NODE] += __popcll(__ballot(mode == M_NODE));
+          pLanes[M_NODE] += __popcll(__ballot(atNode()));
         }
-        if (mode == M_NODE) {
+        if (atNode()) {
           float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
           if (COUNT) cNodes++;
           // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
@@ -791,14 +795,11 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             cur = sc.world[w];
             sptr = stackBase;
           }
-          const bool finished = cur == SRT_REF_DONE, missed = hitRef == SRT_REF_DONE;
-          pend = (finished && missed) ? 1 : pend;
-          mode = finished ? (missed ? M_SHADE : M_HIT) : (cur >= 0 ? M_NODE : M_PRIM);
         }
-      } while (--budget > 0 && __popcll(__ballot(mode == M_NODE)) >= keep);
+      } while (--budget > 0 && __popcll(__ballot(atNode())) >= keep);
     } else if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
-      if (mode == M_PRIM) {
+      if (atPrim()) {
         int pr = ~cur;
         float t;
         bool ok;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       }
     } else if (pick == M_HIT) {
       // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
-      if (mode == M_HIT) {
+      if (atHit()) {
         Record rec;
         int pr = ~hitRef;
         if (pr & 1)
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           attStack[(3 * a.maxBounce + 1) * SRT_BLOCK] = terminal.y;
           attStack[(3 * a.maxBounce + 2) * SRT_BLOCK] = terminal.z;
           pend = 2;
-          mode = M_SHADE;
+          hitRef = SRT_REF_DONE;  // shaded: the lane now waits for a restart step
         } else {
           startTraversal();
         }
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     } else {
       // ------------------------------------------------ path restart: miss / path end (main.cpp:39-40,49-51),
       // pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
-      if (mode == M_SHADE) {
+      if (atRestart()) {
         if (pend != 0) {
           V3 L = background;  // main.cpp:39-40
           if (pend == 2)
@@ -917,10 +918,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
                 *waveQueue = nq;
               }
               nq = __shfl(nq, leader);
-              if (!gotItem && nq < 0) mode = M_EXIT;
+              if (!gotItem && nq < 0) alive = false;
             }
           } else {
-            mode = M_EXIT;
+            alive = false;
           }
           outIndex = -1;
           if (!gotItem) {
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             outIndex = localTile < a.numLocalTiles ? (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln : -1;
           }
         }
-        if (mode != M_EXIT && s < sEnd) {
+        if (alive && s < sEnd) {
           rng.key(seedMixed, pixel, (uint32_t)s);
           float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
           float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211

@@ -217,20 +217,42 @@ __device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V
 // ends tMinA, tMaxA are within eps of the exact ones and the reference's decision (tMax <= tMin ->
 // miss) is certain whenever |tMaxA - tMinA| > eps*(|tMaxA| + |tMinA|), eps = 2^-21 (2.6x the bound).
 // Returns +1 certain hit, -1 certain miss, 0 undecided (the caller then runs the exact test).
+// The min/max chain is written with the hardware instructions directly: fminf/fmaxf make the compiler
+// quiet possible signalling NaNs first (a `v_max_f32 x, x` per live-in operand per visit), which buys
+// nothing here -- v_min/v_max already return the other operand when one is a NaN, and the result only
+// feeds the two comparisons of the certificate.
+__device__ __forceinline__ float hwMin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hwMax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hwMin3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float hwMax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// b: wave-uniform (a kernel argument), read from its scalar register
+__device__ __forceinline__ float hwMaxUniform(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
 __device__ __forceinline__ int boxHitApprox(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax) {
-  float a, b;
-  a = (n0.x - r.o.x) * r1.x;
-  b = (n1.x - r.o.x) * r1.x;
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
-  a = (n0.y - r.o.y) * r1.y;
-  b = (n1.y - r.o.y) * r1.y;
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
-  a = (n0.z - r.o.z) * r1.z;
-  b = (n1.z - r.o.z) * r1.z;
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
+  const float ax = (n0.x - r.o.x) * r1.x, bx = (n1.x - r.o.x) * r1.x;
+  const float ay = (n0.y - r.o.y) * r1.y, by = (n1.y - r.o.y) * r1.y;
+  const float az = (n0.z - r.o.z) * r1.z, bz = (n1.z - r.o.z) * r1.z;
+  tMin = hwMaxUniform(hwMax3(hwMin(ax, bx), hwMin(ay, by), hwMin(az, bz)), tMin);
+  tMax = hwMin(hwMin3(hwMax(ax, bx), hwMax(ay, by), hwMax(az, bz)), tMax);
   const float diff = tMax - tMin;
   const float tol = 0x1p-21f * (fabsf(tMax) + fabsf(tMin));
   return diff > tol ? 1 : (-diff > tol ? -1 : 0);
@@ -787,8 +809,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
           // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
           // miss: take the pending reference
-          int32_t* const up = right != left ? sptr + SRT_BLOCK : sptr;
-          sptr = hitBox ? up : sptr - SRT_BLOCK;
+          int move = hitBox ? (right != left ? 1 : 0) : -1;  // slots; selects of inline constants
+          asm("" : "+v"(move));  // keep it in slots: folded into bytes it needs two literal moves per visit
+          sptr += move * SRT_BLOCK;  // one shift-add
           sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
           cur = hitBox ? left : top;
           if (!singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list

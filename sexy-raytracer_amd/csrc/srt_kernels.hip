@@ -658,7 +658,9 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 // two orders of magnitude from ray to ray).
 enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3, M_HIT = 4 };
 
-template <bool CLOSEST, bool COUNT>
+// SINGLE: the world list is one tree (the usual case, main.cpp:146) -- known at compile time, the per-visit
+// "next root of the world list?" test disappears from the node and primitive steps.
+template <bool CLOSEST, bool COUNT, bool SINGLE>
 __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
   extern __shared__ int32_t lds[];
   // per-thread LDS slots, [slot][thread]: stackDepth+2 traversal slots (slot 0 holds a sentinel, the last
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
   const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
-  const bool singleRoot = sc.numWorld == 1;
+  const bool singleRoot = SINGLE || sc.numWorld == 1;
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
   // scheduler profile (COUNT variant only; wave-uniform)
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   auto popNext = [&]() {
     int next = *sptr;  // the sentinel when nothing is pending
     sptr -= SRT_BLOCK;
-    if (!singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+    if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
       next = sc.world[w];
       sptr = stackBase;
     }
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           sptr += move * SRT_BLOCK;  // one shift-add
           sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
           cur = hitBox ? left : top;
-          if (!singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+          if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
             cur = sc.world[w];
             sptr = stackBase;
           }
@@ -1303,31 +1305,23 @@ int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow,
   return (int)hipGetLastError();
 }
 
+namespace {
+typedef void (*RenderKernel)(const RenderArgs);
+RenderKernel renderVariant(const RenderArgs* a, int traversal, int count) {
+  const bool closest = traversal == SRT_TRAVERSE_CLOSEST, single = a == nullptr || a->scene.numWorld == 1;
+  if (count) return closest ? srt_render_kernel<true, true, false> : srt_render_kernel<false, true, false>;
+  if (single) return closest ? srt_render_kernel<true, false, true> : srt_render_kernel<false, false, true>;
+  return closest ? srt_render_kernel<true, false, false> : srt_render_kernel<false, false, false>;
+}
+}  // namespace
+
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
-  dim3 g(grid), b(SRT_BLOCK);
-  if (traversal == SRT_TRAVERSE_CLOSEST) {
-    if (count)
-      hipLaunchKernelGGL((srt_render_kernel<true, true>), g, b, ldsBytes, stream, *a);
-    else
-      hipLaunchKernelGGL((srt_render_kernel<true, false>), g, b, ldsBytes, stream, *a);
-  } else {
-    if (count)
-      hipLaunchKernelGGL((srt_render_kernel<false, true>), g, b, ldsBytes, stream, *a);
-    else
-      hipLaunchKernelGGL((srt_render_kernel<false, false>), g, b, ldsBytes, stream, *a);
-  }
+  hipLaunchKernelGGL(renderVariant(a, traversal, count), dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, *a);
   return (int)hipGetLastError();
 }
 
 int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU) {
-  hipError_t e;
-  if (traversal == SRT_TRAVERSE_CLOSEST)
-    e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<true, true>, SRT_BLOCK, ldsBytes)
-              : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<true, false>, SRT_BLOCK, ldsBytes);
-  else
-    e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<false, true>, SRT_BLOCK, ldsBytes)
-              : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, srt_render_kernel<false, false>, SRT_BLOCK, ldsBytes);
-  return (int)e;
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, renderVariant(nullptr, traversal, count), SRT_BLOCK, ldsBytes);
 }
 
 int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream) {

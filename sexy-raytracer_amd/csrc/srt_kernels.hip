@@ -780,48 +780,55 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       // several visits per scheduling decision while most of the node lanes are still at nodes
       const int keep = nN - (nN >> 2);
       int budget = a.nodeBurst;
-      do {
-        if (COUNT) {
-          pSteps[M_NODE]++;
-          pLanes[M_NODE] += __popcll(__ballot(atNode()));
-        }
-        if (atNode()) {
-          float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
-          if (COUNT) cNodes++;
-          // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
-          // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
-          const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
-          bool hitBox = sure > 0;
-          if (!rayFast || sure == 0) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
-          if (COUNT && hitBox) cBox++;
-          // descend left and leave right pending, or take the next pending reference (selects, see popNext)
-          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-          if (CLOSEST) {
-            // the closest hit does not depend on the visiting order: take the child on the ray's near side
-            // first (left = lower side of the split axis) so that far subtrees get culled by `closest`
-            const int axis = sc.nodeAxis[cur];
-            const float dAxis = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
-            if (axis < 3 && dAxis < 0.0f) {
-              const int tmp = left;
-              left = right;
-              right = tmp;
+      // two visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
+      // shared by the CU's four SIMDs
+      auto nodeVisit = [&]() {
+          if (COUNT) {
+            pSteps[M_NODE]++;
+            pLanes[M_NODE] += __popcll(__ballot(atNode()));
+          }
+          if (atNode()) {
+            float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
+            if (COUNT) cNodes++;
+            // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
+            // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
+            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
+            bool hitBox = sure > 0;
+            if (!rayFast || sure == 0) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+            if (COUNT && hitBox) cBox++;
+            // descend left and leave right pending, or take the next pending reference (selects, see popNext)
+            int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+            if (CLOSEST) {
+              // the closest hit does not depend on the visiting order: take the child on the ray's near side
+              // first (left = lower side of the split axis) so that far subtrees get culled by `closest`
+              const int axis = sc.nodeAxis[cur];
+              const float dAxis = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
+              if (axis < 3 && dAxis < 0.0f) {
+                const int tmp = left;
+                left = right;
+                right = tmp;
+              }
+            }
+            const int top = *sptr;     // pending reference, or the sentinel
+            sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
+            // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
+            // miss: take the pending reference
+            int move = hitBox ? (right != left ? 1 : 0) : -1;  // slots; selects of inline constants
+            asm("" : "+v"(move));  // keep it in slots: folded into bytes it needs two literal moves per visit
+            sptr += move * SRT_BLOCK;  // one shift-add
+            sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
+            cur = hitBox ? left : top;
+            if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+              cur = sc.world[w];
+              sptr = stackBase;
             }
           }
-          const int top = *sptr;     // pending reference, or the sentinel
-          sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
-          // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
-          // miss: take the pending reference
-          int move = hitBox ? (right != left ? 1 : 0) : -1;  // slots; selects of inline constants
-          asm("" : "+v"(move));  // keep it in slots: folded into bytes it needs two literal moves per visit
-          sptr += move * SRT_BLOCK;  // one shift-add
-          sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
-          cur = hitBox ? left : top;
-          if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
-            cur = sc.world[w];
-            sptr = stackBase;
-          }
-        }
-      } while (--budget > 0 && __popcll(__ballot(atNode())) >= keep);
+      };
+      do {
+        nodeVisit();
+        nodeVisit();
+        budget -= 2;
+      } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
     } else if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
       if (atPrim()) {

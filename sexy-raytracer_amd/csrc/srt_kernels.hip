@@ -30,6 +30,9 @@
 #include "srt_device.h"
 
 #define SRT_BLOCK 256
+#ifndef SRT_NODE_UNROLL
+#define SRT_NODE_UNROLL 4  // node visits per evaluation of the burst loop's exit test
+#endif
 #ifndef SRT_RENDER_WAVES_PER_SIMD
 #define SRT_RENDER_WAVES_PER_SIMD 5
 #endif
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       // several visits per scheduling decision while most of the node lanes are still at nodes
       const int keep = nN - (nN >> 2);
       int budget = a.nodeBurst;
-      // two visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
+      // SRT_NODE_UNROLL visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
       // shared by the CU's four SIMDs
       auto nodeVisit = [&]() {
           if (COUNT) {
@@ -825,9 +828,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           }
       };
       do {
-        nodeVisit();
-        nodeVisit();
-        budget -= 2;
+#pragma unroll
+        for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
+        budget -= SRT_NODE_UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
     } else if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit

@@ -219,7 +219,7 @@ __device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V
 // |x_i - x'_i| <= eps*|x'_i| (tMin and the running closest t are exact), so the approximate interval
 // ends tMinA, tMaxA are within eps of the exact ones and the reference's decision (tMax <= tMin ->
 // miss) is certain whenever |tMaxA - tMinA| > eps*(|tMaxA| + |tMinA|), eps = 2^-21 (2.6x the bound).
-// Returns +1 certain hit, -1 certain miss, 0 undecided (the caller then runs the exact test).
+// Returns the approximate verdict and whether it is uncertain (the caller then runs the exact test).
 // The min/max chain is written with the hardware instructions directly: fminf/fmaxf make the compiler
 // quiet possible signalling NaNs first (a `v_max_f32 x, x` per live-in operand per visit), which buys
 // nothing here -- v_min/v_max already return the other operand when one is a NaN, and the result only
@@ -250,7 +250,7 @@ __device__ __forceinline__ float hwMaxUniform(float a, float b) {
   asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
   return r;
 }
-__device__ __forceinline__ int boxHitApprox(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax) {
+__device__ __forceinline__ bool boxHitApprox(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax, bool& undecided) {
   const float ax = (n0.x - r.o.x) * r1.x, bx = (n1.x - r.o.x) * r1.x;
   const float ay = (n0.y - r.o.y) * r1.y, by = (n1.y - r.o.y) * r1.y;
   const float az = (n0.z - r.o.z) * r1.z, bz = (n1.z - r.o.z) * r1.z;
@@ -258,7 +258,8 @@ __device__ __forceinline__ int boxHitApprox(float4 n0, float4 n1, const Ray& r, 
   tMax = hwMin(hwMin3(hwMax(ax, bx), hwMax(ay, by), hwMax(az, bz)), tMax);
   const float diff = tMax - tMin;
   const float tol = 0x1p-21f * (fabsf(tMax) + fabsf(tMin));
-  return diff > tol ? 1 : (-diff > tol ? -1 : 0);
+  undecided = !(fabsf(diff) > tol);  // also when a NaN got in
+  return diff > tol;
 }
 
 // sphere.h:47-52
@@ -795,9 +796,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             if (COUNT) cNodes++;
             // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
             // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
-            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
-            bool hitBox = sure > 0;
-            if (!rayFast || sure == 0) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+            bool undecided;
+            bool hitBox = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest, undecided);
+            if (!rayFast || undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
             if (COUNT && hitBox) cBox++;
             // descend left and leave right pending, or take the next pending reference (selects, see popNext)
             int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
@@ -1204,9 +1205,9 @@ __global__ __launch_bounds__(SRT_BLOCK, 8) void srt_travbench_kernel(const TravB
           float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
           bool hitBox;
           if (rayFast) {
-            const int sure = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest);
-            hitBox = sure > 0;
-            if (sure == 0) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
+            bool undecided;
+            hitBox = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest, undecided);
+            if (undecided) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
           } else {
             hitBox = boxHit(n0, n1, ray, a.tMin, closest);
           }

@@ -33,6 +33,9 @@
 #ifndef SRT_NODE_UNROLL
 #define SRT_NODE_UNROLL 4  // node visits per evaluation of the burst loop's exit test
 #endif
+#ifndef SRT_NODE_UNROLL_CLOSEST
+#define SRT_NODE_UNROLL_CLOSEST 4  // same for the near-child-first variant (tunable separately)
+#endif
 #ifndef SRT_RENDER_WAVES_PER_SIMD
 #define SRT_RENDER_WAVES_PER_SIMD 5
 #endif
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   float closest = SRT_INF, rayA = 0.0f;
   V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
   bool rayFast = false;
+  int dirNeg = 0;  // CLOSEST: sign bits of ray.d, for the near-child-first order
 
   // next pending reference after the current subtree is done; ends the traversal when none is left.
   // Written with selects rather than nested branches: every divergent `if` costs the wave half a
@@ -749,6 +753,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
               fastDivOperandOk(ray.o.z, ray.d.z);
     rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
+    if (CLOSEST) dirNeg = (ray.d.x < 0.0f ? 1 : 0) | (ray.d.y < 0.0f ? 2 : 0) | (ray.d.z < 0.0f ? 4 : 0);
     closest = SRT_INF;
     hitRef = SRT_REF_DONE;
     sptr = stackBase;
@@ -786,6 +791,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       int budget = a.nodeBurst;
       // SRT_NODE_UNROLL visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
       // shared by the CU's four SIMDs
+      constexpr int UNROLL = CLOSEST ? SRT_NODE_UNROLL_CLOSEST : SRT_NODE_UNROLL;
       auto nodeVisit = [&]() {
           if (COUNT) {
             pSteps[M_NODE]++;
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           }
           if (atNode()) {
             float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
+            const int axis = CLOSEST ? sc.nodeAxis[cur] : 3;  // issued with the node record, used after the box test
             if (COUNT) cNodes++;
             // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
             // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
@@ -805,9 +812,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             if (CLOSEST) {
               // the closest hit does not depend on the visiting order: take the child on the ray's near side
               // first (left = lower side of the split axis) so that far subtrees get culled by `closest`
-              const int axis = sc.nodeAxis[cur];
-              const float dAxis = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
-              if (axis < 3 && dAxis < 0.0f) {
+              // (dirNeg: bit k set when ray.d[k] < 0, bit 3 clear for "no usable axis")
+              if ((dirNeg >> axis) & 1) {
                 const int tmp = left;
                 left = right;
                 right = tmp;
@@ -830,8 +836,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       };
       do {
 #pragma unroll
-        for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
-        budget -= SRT_NODE_UNROLL;
+        for (int u = 0; u < UNROLL; ++u) nodeVisit();
+        budget -= UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
     } else if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit

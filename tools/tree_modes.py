@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 srt = importlib.import_module("sexy-raytracer_amd")
 abi, dev = srt.abi, srt.device()
-W, H, spp, mb = 1280, 720, 2000, 4
+W, H, spp, mb = 1280, 720, int(sys.argv[1]) if len(sys.argv) > 1 else 2000, 4
 ctx = dev.Context(0)
 local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
 for name, builder, trav in (("reference tree, FAITHFUL", abi.SRT_BUILDER_REFERENCE, abi.SRT_TRAVERSE_FAITHFUL),

@@ -787,6 +787,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.shadeMin = envInt("SRT_SHADE_MIN", 16);
   a.primMin = envInt("SRT_PRIM_MIN", 12);
   a.hitMin = envInt("SRT_HIT_MIN", 24);
+  a.fuseMin = envInt("SRT_FUSE_MIN", 32);
   a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 32));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;

@@ -80,6 +80,7 @@ struct RenderArgs {
   int32_t sppChunks;
   int32_t numWork;  // numLocalTiles * sppChunks * 64 (one item = one pixel x one sample chunk)
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
+  int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
   int32_t nodeBurst;          // max node visits per scheduling decision
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // [chunk][localTile][64]

@@ -777,17 +777,60 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     else
       pick = M_NODE;
     pick = __builtin_amdgcn_readfirstlane(pick);
-    const unsigned long long pT0 = COUNT ? clock64() : 0;
-    const int pk = pick == M_HIT ? 2 : pick;  // profile slot: hit shading and restarts share the "shade" row
+    unsigned long long pT0 = COUNT ? clock64() : 0;
+    int pk = pick == M_HIT ? 2 : pick;  // profile slot: hit shading and restarts share the "shade" row
     if (COUNT && pick != M_NODE) {
       pSteps[pk]++;
       pLanes[pk] += pick == M_PRIM ? nP : (pick == M_HIT ? nH : nS);
     }
 
+    int nNodes = nN;
+    if (pick == M_PRIM) {
+      // ------------------------------------------------ sphere::hit / triangle::hit
+      if (atPrim()) {
+        int pr = ~cur;
+        float t;
+        bool ok;
+        if (pr & 1) {
+          if (COUNT) cSph++;
+          const int off = (pr >> 1) * 48;
+          float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
+          V3 center = mk(s0.x, s0.y, s0.z);
+          if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
+            float4 s2 = bufLoad4(rsSpheres, off + 32);
+            center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
+          }
+          ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
+        } else {
+          if (COUNT) cTri++;
+          const int off = (pr >> 1) * 48;
+          ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray,
+                                a.tMin, closest, t);
+        }
+        if (ok) {
+          closest = t;
+          hitRef = cur;
+        }
+        popNext();
+      }
+      // most of these lanes are back at nodes now: go on with a node burst in the same trip instead of
+      // paying for another scheduling decision (scalar work) first
+      nNodes = __popcll(__ballot(atNode()));
+      if (nNodes >= a.fuseMin) {
+        if (COUNT) {
+          const unsigned long long now = clock64();
+          pCyc[pk] += now - pT0;
+          pT0 = now;
+          pk = M_NODE;
+        }
+        pick = M_NODE;
+      }
+    }
+
     if (pick == M_NODE) {
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105
       // several visits per scheduling decision while most of the node lanes are still at nodes
-      const int keep = nN - (nN >> 2);
+      const int keep = nNodes - (nNodes >> 2);
       int budget = a.nodeBurst;
       // SRT_NODE_UNROLL visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
       // shared by the CU's four SIMDs
@@ -839,34 +882,6 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         for (int u = 0; u < UNROLL; ++u) nodeVisit();
         budget -= UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
-    } else if (pick == M_PRIM) {
-      // ------------------------------------------------ sphere::hit / triangle::hit
-      if (atPrim()) {
-        int pr = ~cur;
-        float t;
-        bool ok;
-        if (pr & 1) {
-          if (COUNT) cSph++;
-          const int off = (pr >> 1) * 48;
-          float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
-          V3 center = mk(s0.x, s0.y, s0.z);
-          if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
-            float4 s2 = bufLoad4(rsSpheres, off + 32);
-            center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
-          }
-          ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
-        } else {
-          if (COUNT) cTri++;
-          const int off = (pr >> 1) * 48;
-          ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray,
-                                a.tMin, closest, t);
-        }
-        if (ok) {
-          closest = t;
-          hitRef = cur;
-        }
-        popNext();
-      }
     } else if (pick == M_HIT) {
       // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
       if (atHit()) {
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           startTraversal();
         }
       }
-    } else {
+    } else if (pick == M_SHADE) {
       // ------------------------------------------------ path restart: miss / path end (main.cpp:39-40,49-51),
       // pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
       if (atRestart()) {

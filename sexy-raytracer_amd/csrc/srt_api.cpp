@@ -710,14 +710,14 @@ int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
 }
 
 // Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about 32 samples
-// per item, but at least 128 items per pixel when the samples allow it (never fewer than 2 samples per
-// item).  Many chunks per tile keep the tiles in flight few -- a queue's waves pull consecutive items,
+// per item, but at least 128 items per pixel when there are that many samples (down to one sample per item:
+// 64 spp on the 240p spheres frame run at 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks).  Many chunks per tile keep the tiles in flight few -- a queue's waves pull consecutive items,
 // i.e. the chunks of one tile, then of its neighbour -- and that coherence is worth more than the cost of
 // small items: 625 spp on the headline frame take 200 ms with 20 chunks, 183 ms with 78, 182 ms with 157.
 // History on the 720p/5000-spp frame (single work counter): 1 chunk 563, 8 chunks 1829, 64 chunks 2023,
 // 128-256 chunks 2082-2099, 1000 chunks 1830 Msamples/s.
 int32_t srtDefaultSppChunks(int32_t spp) {
-  const int32_t bySize = (spp + 31) / 32, byCount = std::min(128, spp / 2);
+  const int32_t bySize = (spp + 31) / 32, byCount = std::min(128, spp);
   return std::max(1, std::min(256, std::max(bySize, byCount)));
 }
 

@@ -31,7 +31,7 @@ ctx.render_tiles(p, local.data_ptr(), None)
 torch.cuda.synchronize()
 st = ctx.stats()
 bps = (algorithmic_bytes(st, W, H) - 16 * W * H) / st["samples"]
-p = abi.default_render_params(W, H, spp, mb, seed=1, spp_chunks=0, traversal=trav)
+p = abi.default_render_params(W, H, spp, mb, seed=1, spp_chunks=int(os.environ.get("CHUNKS", "0")), traversal=trav)
 best = 1e30
 for _ in range(3):
     ctx.render_tiles(p, local.data_ptr(), None)

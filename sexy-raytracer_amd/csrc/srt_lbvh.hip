@@ -305,7 +305,7 @@ __global__ void plocInit(const int* sortedVals, const int32_t* refs, const float
   out[i].mx = b;
 }
 
-// nearest neighbour (smallest union area; ties to the lower position) within `radius` places
+// nearest neighbour (smallest union area) within `radius` places
 __global__ __launch_bounds__(PLOC_BLOCK) void plocNearest(const PlocCluster* c, int m, int radius, int* nn) {
   __shared__ float4 sMn[PLOC_BLOCK + 2 * PLOC_MAX_RADIUS], sMx[PLOC_BLOCK + 2 * PLOC_MAX_RADIUS];
   const int first = blockIdx.x * PLOC_BLOCK - radius;
@@ -320,13 +320,17 @@ __global__ __launch_bounds__(PLOC_BLOCK) void plocNearest(const PlocCluster* c, 
   const int i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
   if (i >= m) return;
   const float4 mn = sMn[threadIdx.x + radius], mx = sMx[threadIdx.x + radius];
+  // Ties go to the pair partner i ^ 1 first, then to the lower position.  With "lower position" alone a run
+  // of identical boxes (duplicated geometry) would merge one pair per round; this way it halves.  Some
+  // mutual pair always exists: among the clusters that attain the smallest area, the lowest one either
+  // pairs with its partner or with its lowest candidate b, and b answers with it unless b pairs with b ^ 1.
   float best = 3.0e38f;
   int bestJ = -1;
   const int lo = max(0, i - radius), hi = min(m - 1, i + radius);
   for (int j = lo; j <= hi; ++j) {
     if (j == i) continue;
     const float a = unionArea(mn, mx, sMn[j - first], sMx[j - first]);
-    if (a < best) {
+    if (a < best || (a == best && j == (i ^ 1))) {
       best = a;
       bestJ = j;
     }

@@ -358,6 +358,32 @@ def test_device_lbvh_build_and_closest_hit(ctx, oracle, abi, srt, camera, builde
 
 
 @pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
+def test_device_builders_on_duplicated_geometry(ctx, oracle, abi, srt, builder):
+    """Many identical primitives (equal boxes, equal Morton keys, equal merge costs): the builders must
+    neither fail nor degenerate into one merge per round (the call would not return in test time)."""
+    n = 20000
+    sb = abi.SceneBuilder()
+    mat = sb.pbr(albedo_tex=sb.solid(200, 150, 100), metalness=0.0, roughness=0.5)
+    tri = np.array([[-1.0, 2.0, -1.0], [1.0, 2.0, -1.0], [0.0, 4.0, -1.0]], np.float32)
+    pos = np.tile(tri, (n, 1))
+    pos[3 * (n // 2):] += np.float32(2.5)  # two stacks of identical triangles
+    sb.add_triangles(pos, np.zeros((3 * n, 2), np.float32), np.arange(3 * n, dtype=np.int32).reshape(-1, 3), mat)
+    sb.world_bvh(0, None, 0.0, 1.0, builder=getattr(abi, "SRT_BUILDER_" + builder))
+    ctx.upload_scene(sb)
+    assert _tree_checks(ctx.bvh(0), n)
+    rng = np.random.default_rng(2)
+    rays = np.zeros(2000, abi.RAY_DTYPE)
+    rays["o"] = (0.5, 3.0, 5.0)
+    rays["d"] = rng.normal(size=(len(rays), 3)).astype(np.float32) * np.float32(0.3) + np.array([0.1, 0.0, -1.0], np.float32)
+    rays["tMin"], rays["tMax"] = 0.001, np.inf
+    got = ctx.trace(rays, abi.SRT_TRAVERSE_CLOSEST)
+    want = oracle.OracleScene(sb).trace(rays, abi.SRT_TRAVERSE_CLOSEST)
+    assert np.array_equal(got["prim"] >= 0, want["prim"] >= 0) and (want["prim"] >= 0).any()
+    m = want["prim"] >= 0
+    assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
+
+
+@pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
 def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera, builder):
     for count in (1, 2, 3, 37):
         sb = abi.SceneBuilder()

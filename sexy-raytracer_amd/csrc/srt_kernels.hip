@@ -843,6 +843,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           if (atNode()) {
             float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
             const int axis = CLOSEST ? sc.nodeAxis[cur] : 3;  // issued with the node record, used after the box test
+            const int top = *sptr;  // pending reference, or the sentinel: read while the node record is on its way
             if (COUNT) cNodes++;
             // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
             // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
@@ -862,7 +863,6 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
                 right = tmp;
               }
             }
-            const int top = *sptr;     // pending reference, or the sentinel
             sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
             // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
             // miss: take the pending reference

@@ -737,8 +737,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // next pending reference after the current subtree is done; ends the traversal when none is left.
   // Written with selects rather than nested branches: every divergent `if` costs the wave half a
   // dozen scalar exec-mask instructions, and the scalar unit is shared by the CU's four SIMDs.
-  auto popNext = [&]() {
-    int next = *sptr;  // the sentinel when nothing is pending
+  auto popNext = [&](int next) {  // next = *sptr, read early by the caller: the sentinel when nothing is pending
     sptr -= SRT_BLOCK;
     if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
       next = sc.world[w];
@@ -788,6 +787,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
       if (atPrim()) {
+        const int pending = *sptr;  // for popNext, read while the primitive's record is on its way
         int pr = ~cur;
         float t;
         bool ok;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           closest = t;
           hitRef = cur;
         }
-        popNext();
+        popNext(pending);
       }
       // most of these lanes are back at nodes now: go on with a node burst in the same trip instead of
       // paying for another scheduling decision (scalar work) first

@@ -139,3 +139,12 @@ def test_no_gpu_is_an_error_not_a_fallback(dev):
         dev.lib.srtDestroy(h)
     else:
         assert rc != 0 and not h.value
+
+
+def test_default_chunk_plan(dev):
+    """srtDefaultSppChunks: ~32 samples per item, at least 128 items per pixel when there are that many
+    samples, never more chunks than samples, at most 256 (srt_api.cpp)."""
+    want = {1: 1, 2: 2, 16: 16, 64: 64, 100: 100, 128: 128, 333: 128, 1000: 128, 4096: 128, 5000: 157, 8192: 256, 10 ** 6: 256}
+    for spp, chunks in want.items():
+        assert dev.default_spp_chunks(spp) == chunks, spp
+        assert 1 <= dev.default_spp_chunks(spp) <= spp

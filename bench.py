@@ -33,6 +33,7 @@ WORKLOADS = {
     "spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8),           # configs[1]
     "spheres_240p_64spp": ("spheres", 426, 240, 64, 8),                # configs[0]
     "masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4), # configs[4]
+    "sphere_field_720p_1024spp": ("sphere_field", 1280, 720, 1024, 8),  # not a BASELINE config: main.cpp:92-122
 }
 
 

@@ -151,4 +151,43 @@ def scene_soup(num_triangles, seed=7, extent=6.0, size=0.08, with_ground=True, b
     return sb
 
 
-SCENES = {"spheres": scene_spheres, "iron": scene_iron, "masterchief": scene_masterchief}
+def scene_sphere_field():
+    """The 22x22 field of small spheres that main.cpp:92-122 keeps commented out: moving
+    diffuse spheres (sphere.h:47-52), fuzzy metals, glass, placed with the process-global generator
+    (globals.h:30-35), plus the ground and the three big spheres of main.cpp:90,124-144.  Draws are taken
+    in the order g++ evaluates that code (call arguments right to left); the reference never runs it, so
+    the order is unpinned -- the scene's use is as a parity workload for the features no config exercises."""
+    from . import hipdev  # the global generator lives in the C-ABI library (no GPU needed)
+    rf = hipdev.host_random_float
+    f32 = np.float32
+    hipdev.host_random_reset()
+    sb = SceneBuilder()
+    _ground(sb)
+    glass = sb.dielectric(1.5)
+    for a in range(-11, 11):
+        for b in range(-11, 11):
+            choose = rf()
+            z = f32(b) + f32(0.9) * f32(rf())        # 0.9f * randomFloat()
+            x = f32(a + 0.9 * rf())                  # 0.9 * randomFloat() is a double product
+            center = (float(x), 0.2, float(z))
+            if np.sqrt(f32(x - f32(4.0)) ** 2 + f32(0.0) + z * z) > 0.9:
+                if choose < 0.8:
+                    cz, cy, cx = (f32(rf()) * f32(rf()) for _ in range(3))
+                    mat = sb.pbr(albedo_tex=sb.solid(float(cx) * 255, float(cy) * 255, float(cz) * 255), metalness=0.0, roughness=0.0)
+                    up = f32(0.5) * f32(rf())        # randomFloat(0, 0.5f)
+                    sb.add_sphere(center, 0.2, mat, center1=(center[0], float(f32(0.2) + up), center[2]), time0=0.0, time1=1.0)
+                elif choose < 0.95:
+                    az, ay, ax = (f32(0.5) + f32(0.5) * f32(rf()) for _ in range(3))
+                    fuzz = f32(0.5) * f32(rf())
+                    sb.add_sphere(center, 0.2, sb.metal((float(ax), float(ay), float(az)), float(fuzz)))
+                else:
+                    sb.add_sphere(center, 0.2, glass)
+    sb.add_sphere((-7.0, 4.0, 6.0), 1.0, sb.light((250.2, 220.9, 110.2)))
+    sb.add_sphere((-3.0, 1.0, 0.0), 1.0, sb.pbr(albedo_tex=sb.solid(0.4 * 255, 0.2 * 255, 0.1 * 255), metalness=0.0, roughness=0.0))
+    sb.add_sphere((0.0, 1.0, 0.0), 1.0, glass)
+    sb.add_sphere((3.0, 1.0, 0.0), 1.0, sb.metal((0.7, 0.6, 0.5), 0.0))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+SCENES = {"spheres": scene_spheres, "iron": scene_iron, "masterchief": scene_masterchief, "sphere_field": scene_sphere_field}

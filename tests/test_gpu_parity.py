@@ -208,6 +208,28 @@ def test_render_240p_vs_oracle(ctx, oracle, abi, scenes, camera, name, spp, mb):
         assert_counter(st[k], want_st[k], k)
 
 
+def test_sphere_field_vs_oracle(ctx, oracle, abi, srt, camera):
+    """the 22x22 sphere field main.cpp:92-122 keeps commented out -- 480-odd small spheres,
+    most of them moving (sphere.h:47-52), fuzzy metals and glass, in one bvhNode: same tree as the oracle,
+    render and counters against the oracle with identical counter-RNG keys."""
+    sb = srt.scenes.scene_sphere_field()
+    assert 400 < len(sb.spheres) < 490
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    onodes, depth = osc.bvh(0)
+    assert np.array_equal(ctx.bvh(0), onodes) and ctx.bvh_depth() == depth
+    p = abi.default_render_params(426, 240, 8, 8, seed=31, count_stats=1)
+    acc, rgba = ctx.render_image(p)
+    st = ctx.stats()
+    want_acc, want_rgba, want_st = osc.render(camera, p, oracle.RNG_COUNTER, threads=min(16, os.cpu_count() or 8))
+    assert_accum_close(acc, want_acc)
+    assert_rgba_close(rgba, want_rgba)
+    for k in ("samples", "rays", "nodeVisits", "boxPasses", "triTests", "sphereTests", "shadedTriHits", "texelFetches"):
+        assert_counter(st[k], want_st[k], k)
+    assert st["sphereTests"] > 5 * st["samples"]
+
+
 def test_render_closest_mode_vs_statistics(ctx, abi, scenes, camera):
     """CLOSEST traversal only differs on the F4 rays: images agree except on a few pixels."""
     ctx.upload_scene(scenes["masterchief"])

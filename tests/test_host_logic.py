@@ -148,3 +148,14 @@ def test_default_chunk_plan(dev):
     for spp, chunks in want.items():
         assert dev.default_spp_chunks(spp) == chunks, spp
         assert 1 <= dev.default_spp_chunks(spp) <= spp
+
+
+def test_sphere_field_scene_is_deterministic(srt, oracle, dev):
+    """scene_sphere_field consumes the process-global generator from its reset state: same scene every
+    time, and the product's host BVH builder and the oracle agree on its tree (moving spheres' boxes)."""
+    a, b = srt.scenes.scene_sphere_field(), srt.scenes.scene_sphere_field()
+    assert len(a.spheres) == len(b.spheres) and all(bytes(x) == bytes(y) for x, y in zip(a.spheres, b.spheres))
+    assert any(tuple(s.center0) != tuple(s.center1) for s in a.spheres)
+    nodes, depth = dev.build_bvh_host(a)
+    onodes, odepth = oracle.OracleScene(a).bvh(0)
+    assert np.array_equal(nodes, onodes) and depth >= odepth

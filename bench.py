@@ -26,6 +26,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
+DATA_NOTE = {
+    "masterchief": "synthetic (assets/masterchief2 mesh + seeded procedural iron textures)",
+    "iron": "synthetic (seeded procedural iron textures)",
+    "spheres": "synthetic (procedural scene, no assets)",
+    "sphere_field": "synthetic (procedural scene placed with the reference's generator, no assets)",
+}
+
 WORKLOADS = {
     # name: (scene, W, H, spp, maxBounce)
     "masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4),   # configs[3], the headline
@@ -149,6 +156,9 @@ def main():
     ctx = dev.Context(local_rank)
     sb = srt.scenes.SCENES[scene_name]()
     ctx.upload_scene(sb)  # scene resident in HBM before the timed region
+    n_tris = int(sb.desc().numTriangles)
+    scene_footprint = "BVH %.0f KB, %d triangles %.0f KB, %d spheres, textures %.1f MB" % (
+        len(ctx.bvh(0)) * 32 / 1e3, n_tris, n_tris * 112 / 1e3, len(sb.spheres), len(sb.texels) / 1e6)
     cam_params = abi.default_camera_params()
     ctx.set_camera(dev.make_camera(cam_params))
 
@@ -220,19 +230,19 @@ def main():
                       else "Msamples/s (WxHxspp/s), " + args.workload,
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (assets/masterchief2 mesh + seeded procedural iron textures)",
+            "vs_baseline": None, "dtype": "f32", "data": DATA_NOTE.get(scene_name, "synthetic"),
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": spp,
                        "max_bounce": max_bounce, "seed": args.seed, "spp_chunks": chunks, "traversal": "faithful (bvh.h order)",
                        "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "srt_render_kernel<false,false>", "kernel_ms_avg": round(avg_kernel_ms, 3),
+                         "kernel": "srt_render_kernel<false,false,true>", "kernel_ms_avg": round(avg_kernel_ms, 3),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
                          "rays_per_sample": round(st["rays"] / st["samples"], 4),
                          "node_visits_per_ray": round(st["nodeVisits"] / st["rays"], 3),
                          "prim_tests_per_ray": round((st["triTests"] + st["sphereTests"]) / st["rays"], 3),
-                         "note": "scene is cache-resident (BVH 129 KB, triangles 335 KB, textures 4.6 MB): "
-                                 "achieved = algorithmic bytes / kernel time, not HBM traffic"},
+                         "note": "scene is cache-resident (%s): achieved = algorithmic bytes / kernel time, "
+                                 "not HBM traffic" % scene_footprint},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):

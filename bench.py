@@ -10,14 +10,36 @@
   N GPUs   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
            strong scaling: the frame is fixed, tiles shard across ranks.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  The CPU oracle is used
-only for the `cpu_baseline` leg (a reported baseline on a bounded sample, never the thing timed
-as `value`)."""
+Prints ONE JSON line on rank 0.  `roofline` names the roof that binds the workload:
+  * the BASELINE configs are cache-resident (BVH 129 KB): bound = "valu-issue".  achieved = VALU
+    wave-instructions per second (hardware counter SQ_INSTS_VALU of one launch / the kernel time measured
+    live with HIP events), peak = CUs x 4 SIMDs x clock / 2 cycles per wave64 instruction
+    (MI355X_MICROARCH.md: SIMD-32, 2 cycles), lane_utilisation = SQ_THREAD_CYCLES_VALU /
+    (64 x SQ_ACTIVE_INST_VALU), frac = issue fraction x lane utilisation = useful lane-operations over
+    the chip's lane-operation peak.  The algorithmic-bytes figure of SURVEY 8(d) is kept as
+    `algorithmic_GBps` (it exceeds the HBM peak because the bytes come from L1/L2) and is never `frac`.
+  * the synthetic soups (1-10 M triangles, far larger than the caches) are HBM-bound: bound = "hbm",
+    achieved = algorithmic bytes / kernel time, frac = achieved / 8 TB/s, and the measured HBM side
+    next to it (`traffic` bytes per launch, `hbm_measured_GBps`, `hbm_measured_frac`).
+Counters are collected IN THIS RUN by child processes under `rocprofv3 --pmc` (separate passes for
+FETCH_SIZE, WRITE_SIZE and the SQ group, never combined with tracing) before the parent touches the
+GPU; if that is not possible (N > 1, already running under a profiler, rocprofv3 missing or failing)
+the values recorded under profiles/ by an earlier run of the same kernel source are used and
+`counters_source` says so.
+
+The CPU oracle is used only for the `cpu_baseline` leg (a reported baseline on a bounded sample,
+never the thing timed as `value`)."""
 import argparse
+import csv
+import glob
+import hashlib
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,23 +47,50 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_CYCLES_PER_WAVE_INSTR = 2.0  # wave64 on a SIMD-32 (MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc")
+SIMDS_PER_CU = 4
 
 DATA_NOTE = {
     "masterchief": "synthetic (assets/masterchief2 mesh + seeded procedural iron textures)",
     "iron": "synthetic (seeded procedural iron textures)",
     "spheres": "synthetic (procedural scene, no assets)",
     "sphere_field": "synthetic (procedural scene placed with the reference's generator, no assets)",
+    "soup": "synthetic (seeded uniform triangle soup, seed 7)",
 }
 
+# name: (scene, W, H, spp, maxBounce, tree builder, traversal, binding roof)
 WORKLOADS = {
-    # name: (scene, W, H, spp, maxBounce)
-    "masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4),   # configs[3], the headline
-    "iron_720p_5000spp": ("iron", 1280, 720, 5000, 4),                 # configs[2]
-    "spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8),           # configs[1]
-    "spheres_240p_64spp": ("spheres", 426, 240, 64, 8),                # configs[0]
-    "masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4), # configs[4]
-    "sphere_field_720p_1024spp": ("sphere_field", 1280, 720, 1024, 8),  # not a BASELINE config: main.cpp:92-122
+    "masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4, "reference", "faithful", "valu-issue"),   # configs[3], the headline
+    "iron_720p_5000spp": ("iron", 1280, 720, 5000, 4, "reference", "faithful", "valu-issue"),                 # configs[2]
+    "spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8, "reference", "faithful", "valu-issue"),           # configs[1]
+    "spheres_240p_64spp": ("spheres", 426, 240, 64, 8, "reference", "faithful", "valu-issue"),                # configs[0]
+    "masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4, "reference", "faithful", "valu-issue"), # configs[4]
+    "sphere_field_720p_1024spp": ("sphere_field", 1280, 720, 1024, 8, "reference", "faithful", "valu-issue"),  # main.cpp:92-122
+    # HBM-bound points (SURVEY 8d "Synthetic"): the parity path (reference tree, bvh.h order) and the
+    # fast mode (device-built PLOC tree, closest-hit traversal)
+    "soup_1m_720p_16spp": ("soup:1000000", 1280, 720, 16, 4, "reference", "faithful", "hbm"),
+    "soup_4m_720p_16spp": ("soup:4000000", 1280, 720, 16, 4, "reference", "faithful", "hbm"),
+    "soup_10m_720p_16spp": ("soup:10000000", 1280, 720, 16, 4, "reference", "faithful", "hbm"),
+    "soup_1m_ploc_closest_720p_16spp": ("soup:1000000", 1280, 720, 16, 4, "ploc", "closest", "hbm"),
+    "soup_4m_ploc_closest_720p_16spp": ("soup:4000000", 1280, 720, 16, 4, "ploc", "closest", "hbm"),
+    "soup_10m_ploc_closest_720p_16spp": ("soup:10000000", 1280, 720, 16, 4, "ploc", "closest", "hbm"),
 }
+
+PMC_PASSES = [
+    ("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]),
+    ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
+    ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+            "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES"]),
+]
+
+
+def build_scene(srt, scene_name, builder):
+    abi = srt.abi
+    if scene_name.startswith("soup:"):
+        n = int(scene_name.split(":")[1])
+        b = {"reference": abi.SRT_BUILDER_REFERENCE, "lbvh": abi.SRT_BUILDER_LBVH, "ploc": abi.SRT_BUILDER_PLOC}[builder]
+        return srt.scenes.scene_soup(n, seed=7, extent=6.0, size=max(0.01, 0.08 * (100000.0 / n) ** (1.0 / 3.0)), builder=b)
+    return srt.scenes.SCENES[scene_name]()
 
 
 def gather_tiles(local, rank, world):
@@ -71,9 +120,19 @@ def algorithmic_bytes(stats, width, height):
             + 24 * stats["shadedTriHits"] + 4 * stats["texelFetches"] + 16 * width * height)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sb, cam_params, abi, width, height, spp_full, max_bounce, seed, budget_s=20.0):
     """The CPU oracle (a port of the reference's loop) on this box's host cores, on a bounded sample
-    of the same frame: all 1280x720 pixels at a reduced spp sized for ~budget_s of CPU work."""
+    of the same frame: all pixels at a reduced spp sized for ~budget_s of CPU work."""
     import oracle.oracle_py as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -99,10 +158,149 @@ def cpu_baseline(sb, cam_params, abi, width, height, spp_full, max_bounce, seed,
     osc.render(cam, p, O.RNG_COUNTER, threads=cores, want_rgba=False, want_stats=False)
     dt = time.time() - t
     return {"value": round(width * height * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d all pixels at %d spp of %d (%.1f s, OpenMP over rows, counter RNG, g++ -O2)" % (
+            "sample": "%dx%d all pixels at %d spp of %d (%.1f s, OpenMP over rows, counter RNG)" % (
                 width, height, spp, spp_full, dt),
+            "cpu_model": cpu_model(), "compiler": "g++ -O2 -ffp-contract=off (oracle/Makefile)",
             "single_thread_value": round(single, 4),
             "single_thread_sample": "rows %d..%d at 2 spp" % rows}
+
+
+# ---------------------------------------------------------------------------------------- counters
+def kernel_source_id():
+    """Identifies the kernel build the counters belong to: hash of the kernel sources and build flags."""
+    h = hashlib.sha256()
+    for rel in ("sexy-raytracer_amd/csrc/srt_kernels.hip", "sexy-raytracer_amd/csrc/srt_device.h",
+                "sexy-raytracer_amd/csrc/Makefile"):
+        try:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+        except OSError:
+            pass
+    return h.hexdigest()[:16]
+
+
+def pmc_file(workload):
+    return os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+
+
+def under_profiler():
+    env = os.environ
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in env) or "rocprof" in env.get("LD_PRELOAD", "")
+
+
+def collect_pmc(args, workload, spp, timeout_s):
+    """Runs this script as `--pmc-child` under `rocprofv3 --pmc <group>` once per counter group and
+    returns {counter: value per render-kernel launch}.  Must be called before this process touches the
+    GPU (the children are separate processes; nothing is exec'ed from a GPU-initialised one)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_"))}
+    env.pop("LD_PRELOAD", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["TMPDIR"] = "/tmp"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="srt_pmc_", dir="/tmp")
+    try:
+        for name, counters in PMC_PASSES:
+            d = os.path.join(tmp, name)
+            cmd = [rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable,
+                                                  os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload,
+                                                  "--spp", str(spp), "--seed", str(args.seed), "--spp-chunks", str(args.spp_chunks)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 pass '%s' failed (rc %d): %s" % (name, r.returncode, r.stdout.decode(errors="replace")[-400:]))
+            acc, cnt = {}, {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "srt_render_kernel" not in row["Kernel_Name"]:
+                        continue
+                    c = row["Counter_Name"]
+                    acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+                    cnt[c] = cnt.get(c, 0) + 1
+            if not acc:
+                raise RuntimeError("rocprofv3 pass '%s' recorded no render-kernel dispatch" % name)
+            for c in acc:
+                out[c] = acc[c] / cnt[c]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def pmc_child(args):
+    """One launch of the workload's render kernel (after one untimed warm-up launch at 1 spp), for the
+    profiler wrapped around this process to count."""
+    import torch
+    srt = importlib.import_module("sexy-raytracer_amd")
+    abi, dev = srt.abi, srt.device()
+    scene_name, W, H, spp, max_bounce, builder, traversal, _ = WORKLOADS[args.workload]
+    if args.spp > 0:
+        spp = args.spp
+    trav = abi.SRT_TRAVERSE_CLOSEST if traversal == "closest" else abi.SRT_TRAVERSE_FAITHFUL
+    ctx = dev.Context(0)
+    ctx.upload_scene(build_scene(srt, scene_name, builder))
+    ctx.set_camera(dev.make_camera(abi.default_camera_params()))
+    local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+    chunks = max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else 0
+    p = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, spp_chunks=chunks, traversal=trav)
+    ctx.render_tiles(p, local.data_ptr(), None)
+    torch.cuda.synchronize()
+    ctx.close()
+
+
+def roofline_block(bound, pmc, pmc_source, avg_kernel_ms, alg_bytes_per_launch, bytes_per_sample, st, info, scene_footprint,
+                   kernel_name):
+    alg_gbps = alg_bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+    common = {"kernel": kernel_name, "kernel_ms_avg": round(avg_kernel_ms, 3),
+              "algorithmic_bytes_per_sample": round(bytes_per_sample, 2), "algorithmic_GBps": round(alg_gbps, 1),
+              "rays_per_sample": round(st["rays"] / max(1, st["samples"]), 4),
+              "node_visits_per_ray": round(st["nodeVisits"] / max(1, st["rays"]), 3),
+              "prim_tests_per_ray": round((st["triTests"] + st["sphereTests"]) / max(1, st["rays"]), 3),
+              "counters_source": pmc_source, "scene_footprint": scene_footprint}
+    traffic = None
+    if pmc and "FETCH_SIZE" in pmc:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 tallies a 128-B read request at 64 B
+        # (MI355X_MICROARCH.md, HBM): the streaming-read correction is x2; 32-B node gathers are narrower
+        # than that, so both figures are kept.
+        fetch, write = pmc["FETCH_SIZE"] * 1024.0, pmc.get("WRITE_SIZE", 0.0) * 1024.0
+        traffic = int(2 * fetch + write)
+        common["traffic_uncorrected"] = int(fetch + write)
+        common["traffic_note"] = ("FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE; "
+                                  "traffic_uncorrected = FETCH_SIZE + WRITE_SIZE as read")
+    if bound == "hbm":
+        r = {"bound": "hbm", "achieved": round(alg_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(alg_gbps / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if traffic is not None:
+            lo = common["traffic_uncorrected"] / (avg_kernel_ms * 1e-3) / 1e9
+            hi = traffic / (avg_kernel_ms * 1e-3) / 1e9
+            r["hbm_measured_GBps"] = round(lo, 1)            # FETCH_SIZE as read (node gathers are 32-64 B requests)
+            r["hbm_measured_frac"] = round(lo / HBM_PEAK_GBS, 4)
+            r["hbm_measured_GBps_x2"] = round(hi, 1)         # with the streaming-read doubling
+        r.update(common)
+        return r
+    # cache-resident: VALU issue x lane utilisation
+    r = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": traffic}
+    if pmc and "SQ_INSTS_VALU" in pmc:
+        clock_ghz = info["clock_mhz"] / 1e3
+        if "GRBM_GUI_ACTIVE" in pmc:  # summed over the 8 XCDs
+            clock_ghz = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc.get("_kernel_ms", avg_kernel_ms) * 1e-3) / 1e9
+            if not (1.0 < clock_ghz < 3.0):
+                clock_ghz = info["clock_mhz"] / 1e3
+        peak = info["cus"] * SIMDS_PER_CU * clock_ghz / VALU_CYCLES_PER_WAVE_INSTR
+        achieved = pmc["SQ_INSTS_VALU"] / (avg_kernel_ms * 1e-3) / 1e9
+        lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+        r.update({"achieved": round(achieved, 2), "peak": round(peak, 2), "issue_frac": round(achieved / peak, 4),
+                  "lane_utilisation": round(lane, 4), "frac": round(achieved / peak * lane, 4),
+                  "clock_ghz": round(clock_ghz, 3),
+                  "valu_wave_instr_per_sample": round(pmc["SQ_INSTS_VALU"] / max(1, pmc.get("_samples", 1)), 2),
+                  "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in pmc else None,
+                  "salu_per_valu": round(pmc["SQ_INSTS_SALU"] / pmc["SQ_INSTS_VALU"], 4) if "SQ_INSTS_SALU" in pmc else None})
+    if traffic is not None:
+        r["hbm_measured_frac"] = round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    r["note"] = ("frac = VALU issue fraction x lane utilisation (useful lane-operations / chip lane-operation peak); "
+                 "the scene is cache-resident, algorithmic_GBps is served by L1/L2 and is not an HBM fraction")
+    r.update(common)
+    return r
 
 
 def main():
@@ -116,15 +314,21 @@ def main():
     ap.add_argument("--spp-chunks", type=int, default=0,
                     help="work items per pixel: samples of a pixel are summed in index order inside a chunk and the "
                          "chunk sums in chunk order (1 = the reference's single running sum, main.cpp:217; "
-                         "0 = the library default, ~32 samples per item)")
+                         "0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect hardware counters in this run (use profiles/)")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--save-pmc", action="store_true", help="record the counters of this run under profiles/pmc_<workload>.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--save-png", default="")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    # before anything initialises HIP/HSA in this process: dmabuf IPC for RCCL
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.pmc_child:
+        return pmc_child(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +337,36 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    scene_name, W, H, spp, max_bounce, builder, traversal, bound = WORKLOADS[args.workload]
+    if args.spp > 0:
+        spp = args.spp
+
+    # ---- hardware counters of one launch of this workload, collected by child processes before this
+    # process initialises the GPU
+    pmc, pmc_source = None, "none"
+    ksrc = kernel_source_id()
+    if world == 1 and not args.no_pmc and not under_profiler():
+        try:
+            t = time.time()
+            pmc = collect_pmc(args, args.workload, spp, args.pmc_timeout)
+            pmc_source = "in-run: rocprofv3 --pmc, %d separate passes, one launch each (%.0f s)" % (len(PMC_PASSES), time.time() - t)
+        except Exception as e:  # fall back to the recorded counters, and say so
+            sys.stderr.write("bench.py: in-run counter collection failed: %s\n" % e)
+            pmc = None
+    if pmc is None:
+        try:
+            rec = json.load(open(pmc_file(args.workload)))
+            if rec.get("spp") == spp and world == 1:
+                pmc = rec["counters"]
+                same = rec.get("kernel_source_id") == ksrc
+                pmc_source = "from %s (recorded %s; kernel source %s this build)" % (
+                    os.path.relpath(pmc_file(args.workload), ROOT), rec.get("recorded", "?"), "matches" if same else "DIFFERS from")
+        except (OSError, ValueError, KeyError):
+            pmc = None
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the hot path)")
     backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only to rehearse N ranks on one GPU
@@ -140,8 +374,6 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -149,16 +381,18 @@ def main():
 
     srt = importlib.import_module("sexy-raytracer_amd")
     abi, dev = srt.abi, srt.device()
-    scene_name, W, H, spp, max_bounce = WORKLOADS[args.workload]
-    if args.spp > 0:
-        spp = args.spp
+    trav = abi.SRT_TRAVERSE_CLOSEST if traversal == "closest" else abi.SRT_TRAVERSE_FAITHFUL
 
     ctx = dev.Context(local_rank)
-    sb = srt.scenes.SCENES[scene_name]()
+    info = ctx.device_info()
+    t_build = time.time()
+    sb = build_scene(srt, scene_name, builder)
     ctx.upload_scene(sb)  # scene resident in HBM before the timed region
+    t_build = time.time() - t_build
     n_tris = int(sb.desc().numTriangles)
+    n_nodes = len(ctx.bvh(0)) if n_tris < 2000000 else 2 * n_tris
     scene_footprint = "BVH %.0f KB, %d triangles %.0f KB, %d spheres, textures %.1f MB" % (
-        len(ctx.bvh(0)) * 32 / 1e3, n_tris, n_tris * 112 / 1e3, len(sb.spheres), len(sb.texels) / 1e6)
+        n_nodes * 32 / 1e3, n_tris, n_tris * 112 / 1e3, len(sb.spheres), len(sb.texels) / 1e6)
     cam_params = abi.default_camera_params()
     ctx.set_camera(dev.make_camera(cam_params))
 
@@ -167,7 +401,7 @@ def main():
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
     chunks = max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else dev.default_spp_chunks(spp)
     params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
-                                       spp_chunks=chunks if args.spp_chunks > 0 else 0)  # 0 = library plan
+                                       spp_chunks=chunks if args.spp_chunks > 0 else 0, traversal=trav)  # 0 = library plan
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms = []
 
@@ -208,7 +442,7 @@ def main():
     # seed at a reduced spp (outside the timed region); the traversal is identical sample for sample.
     count_spp = min(spp, 8)
     cparams = abi.default_render_params(W, H, count_spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
-                                        count_stats=1)
+                                        count_stats=1, traversal=trav)
     ctx.render_tiles(cparams, local.data_ptr(), stream)
     torch.cuda.synchronize()
     st = ctx.stats()
@@ -222,37 +456,34 @@ def main():
         bytes_per_sample = (algorithmic_bytes(st, W, H) - 16 * W * H) / samples_counted
         samples_per_launch = W * H * spp  # whole frame; per rank it is 1/world of this
         bytes_per_launch = (bytes_per_sample * samples_per_launch + 16 * W * H) / world
-        achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+        if pmc is not None:
+            pmc = dict(pmc)
+            pmc["_samples"] = samples_per_launch
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
+        kernel_name = "srt_render_kernel<%s,false,true>" % ("true" if traversal == "closest" else "false")
         line = {
             "metric": "Msamples/s (WxHxspp/s), 720p masterchief @5k spp" if args.workload == "masterchief_720p_5000spp"
                       else "Msamples/s (WxHxspp/s), " + args.workload,
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": DATA_NOTE.get(scene_name, "synthetic"),
+            "vs_baseline": None, "dtype": "f32", "data": DATA_NOTE.get(scene_name.split(":")[0], "synthetic"),
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": spp,
-                       "max_bounce": max_bounce, "seed": args.seed, "spp_chunks": chunks, "traversal": "faithful (bvh.h order)",
+                       "max_bounce": max_bounce, "seed": args.seed, "spp_chunks": chunks,
+                       "tree": builder, "traversal": "faithful (bvh.h order)" if traversal == "faithful" else "closest hit (not the parity path)",
+                       "scene_build_upload_s": round(t_build, 2),
                        "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "srt_render_kernel<false,false,true>", "kernel_ms_avg": round(avg_kernel_ms, 3),
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
-                         "rays_per_sample": round(st["rays"] / st["samples"], 4),
-                         "node_visits_per_ray": round(st["nodeVisits"] / st["rays"], 3),
-                         "prim_tests_per_ray": round((st["triTests"] + st["sphereTests"]) / st["rays"], 3),
-                         "note": "scene is cache-resident (%s): achieved = algorithmic bytes / kernel time, "
-                                 "not HBM traffic" % scene_footprint},
+            "device": info,
+            "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
+                                       scene_footprint, kernel_name),
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tf = json.load(open(traffic_file))
-                if tf.get("workload") == args.workload and tf.get("spp") == spp and world == 1:
-                    line["roofline"]["traffic"] = tf["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = tf.get("source", "profiles/traffic.json")
-            except Exception:
-                pass
+        if args.save_pmc and pmc is not None and pmc_source.startswith("in-run"):
+            rec = {"workload": args.workload, "spp": spp, "spp_chunks": chunks, "kernel_source_id": ksrc,
+                   "recorded": time.strftime("%Y-%m-%d"), "device": info, "kernel_ms_at_recording": round(avg_kernel_ms, 3),
+                   "counters": {k: v for k, v in pmc.items() if not k.startswith("_")},
+                   "how": "bench.py --save-pmc: rocprofv3 --pmc, separate passes %s" % [c for _, c in PMC_PASSES]}
+            os.makedirs(os.path.dirname(pmc_file(args.workload)), exist_ok=True)
+            json.dump(rec, open(pmc_file(args.workload), "w"), indent=1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sb, cam_params, abi, W, H, spp, max_bounce, args.seed, args.cpu_budget)
         else:

@@ -286,23 +286,6 @@ int srtRenderImage(SrtContext* ctx, const SrtRenderParams* p, float* hAccum, uin
 /* Fixed-ray-set parity entry: world.hit(r, tMin, tMax, rec) for n rays. HOST pointers. */
 int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, int32_t traversal);
 
-/* Test hook: material::scatter + emitted (material.h:15-21) through the kernel's own
- * shading function for n (ray, hit record) pairs; entry i draws from the counter RNG
- * keyed (seed, pixel=i, sample=0).  out13 per entry: attenuation[3], scattered dir[3],
- * scattered origin[3], scatter's bool, emitted[3].  HOST pointers. */
-int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
-
-/* Test hook: the slab test's per-ray-reciprocal division (srt_kernels.hip fastDiv) next to the
- * plain IEEE division on count operand pairs.  HOST pointers. */
-int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
-
-/* Design probe (not part of the render path): throughput of a traversal-only kernel (the render kernel's
- * node / primitive steps with lanes pulling rays from an array) on a caller-supplied ray set, processed
- * `reps` times.  Single-root scenes with static spheres.  msOut = kernel time; tOut/refOut (optional, n
- * entries) = hit distance and device primitive reference per ray. */
-int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut,
-                     int32_t* refOut);
-
 /* Duration of the most recent srtRenderTiles kernel, from HIP events recorded
  * on its stream (synchronises on the stop event). */
 int srtLastKernelMs(SrtContext* ctx, float* ms);

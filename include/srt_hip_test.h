@@ -1,0 +1,47 @@
+/*
+ * srt_hip_test.h -- test hooks and diagnostics of libsrt_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/srt_hip.h): nothing here is needed to render.  These entry
+ * points let the parity tests reach device functions of the hot path in isolation (the kernel's own
+ * shading function, its slab-test division, the render kernel's own traversal per ray) and let the
+ * measurement tools vary the work distribution.  HOST pointers throughout.
+ */
+#ifndef SRT_HIP_TEST_H
+#define SRT_HIP_TEST_H
+
+#include "srt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: material::scatter + emitted (material.h:15-21) through the kernel's own
+ * shading function for n (ray, hit record) pairs; entry i draws from the counter RNG
+ * keyed (seed, pixel=i, sample=0).  out13 per entry: attenuation[3], scattered dir[3],
+ * scattered origin[3], scatter's bool, emitted[3].  HOST pointers. */
+int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
+
+/* Test hook: the slab test's per-ray-reciprocal division (srt_kernels.hip fastDiv) next to the
+ * plain IEEE division on count operand pairs.  HOST pointers. */
+int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
+
+/* Design probe (not part of the render path): throughput of a traversal-only kernel (the render kernel's
+ * node / primitive steps with lanes pulling rays from an array) on a caller-supplied ray set, processed
+ * `reps` times.  Single-root scenes with static spheres.  msOut = kernel time; tOut/refOut (optional, n
+ * entries) = hit distance and device primitive reference per ray. */
+int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut,
+                     int32_t* refOut);
+
+/* Per-context diagnostic tunables of the work distribution and the wave scheduler ("queues", "unit_tiles",
+ * "tile_block", "shade_min", "prim_min", "hit_min", "fuse_min", "node_burst", "ploc_radius", "fast_div",
+ * "max_live_chunks").  Defaults come from the library (and, for the scheduler thresholds, from SRT_*
+ * environment variables read ONCE at srtCreate); none of them changes the image
+ * (tests/test_gpu_properties.py::test_image_independent_of_work_distribution).  "tile_block" has no
+ * environment override: every rank and the host untile (tiles.py) must agree on it. */
+int srtSetTunable(SrtContext* ctx, const char* name, int32_t value);
+int srtGetTunable(SrtContext* ctx, const char* name, int32_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_HIP_TEST_H */

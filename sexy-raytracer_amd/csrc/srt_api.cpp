@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <random>
 #include <string>
@@ -220,9 +221,20 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// Diagnostic tunables of the work distribution and the wave scheduler.  Environment variables give the
+// defaults ONCE, at srtCreate; srtSetTunable (include/srt_hip_test.h) changes them per context.  -1 = the
+// library's own rule.
+struct Tunables {
+  int tileBlock, unitTiles, queues;
+  int shadeMin, primMin, hitMin, fuseMin, nodeBurst;
+  int plocRadius, fastDiv;
+  int maxLiveChunks;
+};
+
 struct SrtContext {
   int device = 0;
   std::string error;
+  Tunables tun{};
   hipDeviceProp_t prop;
   // device scene
   std::vector<DeviceBuffer> sceneBuffers;
@@ -286,6 +298,26 @@ int envInt(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+struct TunableName {
+  const char* name;
+  const char* env;
+  int Tunables::*field;
+  int dflt;
+};
+const TunableName kTunables[] = {
+    {"tile_block", nullptr, &Tunables::tileBlock, SRT_TILE_BLOCK},  // no environment override: ranks must agree (tiles.py)
+    {"unit_tiles", "SRT_UNIT_TILES", &Tunables::unitTiles, -1},
+    {"queues", "SRT_QUEUES", &Tunables::queues, -1},
+    {"shade_min", "SRT_SHADE_MIN", &Tunables::shadeMin, 16},
+    {"prim_min", "SRT_PRIM_MIN", &Tunables::primMin, 12},
+    {"hit_min", "SRT_HIT_MIN", &Tunables::hitMin, 24},
+    {"fuse_min", "SRT_FUSE_MIN", &Tunables::fuseMin, 32},
+    {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 32},
+    {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
+    {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
+    {"max_live_chunks", "SRT_MAX_LIVE_CHUNKS", &Tunables::maxLiveChunks, -1},
+};
+
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
   // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
   return (size_t)(ctx->scene.stackDepth + 2 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
@@ -297,6 +329,16 @@ size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
 namespace {
 // every index the kernels (and the host builder) will follow
 int validateScene(SrtContext* ctx, const SrtSceneDesc* d) {
+  // counts and pointers first: everything below indexes these arrays and sizes std::vectors with the counts
+  if (d->numTriangles < 0 || d->numSpheres < 0 || d->numPrims < 0 || d->numWorld < 0 || d->numMaterials < 0 ||
+      d->numTextures < 0 || d->numTexelBytes < 0)
+    return fail(ctx, "scene: negative element count");
+  if ((d->numTriangles > 0 && !d->triangles) || (d->numSpheres > 0 && !d->spheres) || (d->numPrims > 0 && !d->prims) ||
+      (d->numWorld > 0 && !d->world) || (d->numMaterials > 0 && !d->materials) || (d->numTextures > 0 && !d->textures) ||
+      (d->numTexelBytes > 0 && !d->texels))
+    return fail(ctx, "scene: null array with a non-zero count");
+  if ((int64_t)d->numTriangles > 0x3fffffff || (int64_t)d->numSpheres > 0x3fffffff)
+    return fail(ctx, "scene: too many primitives for 31-bit device references");
   for (int i = 0; i < d->numTextures; ++i) {
     const SrtTextureIn& t = d->textures[i];
     if (t.kind == SRT_TEX_CHECKER) {
@@ -337,12 +379,22 @@ int validateScene(SrtContext* ctx, const SrtSceneDesc* d) {
       return fail(ctx, "world item %d: bad range", w);
     if (it.kind == SRT_WORLD_BVH && it.nodes) {
       // a caller-built tree must be finite and acyclic: children point forward (pre-order)
+      // ... and a tree: every node but the root has exactly one parent (the pending-stack capacity is
+      // derived per node from its single parent, buildItem)
       if (it.numNodes < 1) return fail(ctx, "world item %d: prebuilt tree without nodes", w);
-      for (int i = 0; i < it.numNodes; ++i)
-        for (int32_t c : {it.nodes[i].left, it.nodes[i].right}) {
+      std::vector<uint8_t> parents(it.numNodes, 0);
+      for (int i = 0; i < it.numNodes; ++i) {
+        const int32_t l = it.nodes[i].left, r = it.nodes[i].right;
+        for (int32_t c : {l, r}) {
           if (c >= 0 ? (c <= i || c >= it.numNodes) : (~c < it.first || ~c >= it.first + it.count))
             return fail(ctx, "world item %d: prebuilt node %d has a bad child reference %d", w, i, c);
         }
+        if (l >= 0 && ++parents[l] > 1) return fail(ctx, "world item %d: prebuilt node %d has more than one parent", w, l);
+        if (r >= 0 && r != l && ++parents[r] > 1) return fail(ctx, "world item %d: prebuilt node %d has more than one parent", w, r);
+        if (r >= 0 && r == l) return fail(ctx, "world item %d: prebuilt node %d lists one subtree twice", w, i);
+      }
+      for (int i = 1; i < it.numNodes; ++i)
+        if (!parents[i]) return fail(ctx, "world item %d: prebuilt node %d is unreachable", w, i);
     }
   }
 
@@ -361,6 +413,7 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   if (deviceOrdinal < 0 || deviceOrdinal >= n) return fail(nullptr, "device ordinal %d out of range [0,%d)", deviceOrdinal, n);
   SrtContext* ctx = new SrtContext();
   ctx->device = deviceOrdinal;
+  for (const TunableName& t : kTunables) ctx->tun.*(t.field) = t.env ? envInt(t.env, t.dflt) : t.dflt;
   HIP_OK(ctx, hipSetDevice(deviceOrdinal));
   HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
   HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, SRT_MAX_QUEUES * 16 * sizeof(int32_t)));
@@ -429,7 +482,7 @@ int srtSetCamera(SrtContext* ctx, const SrtCamera* c) {
   return 0;
 }
 
-int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
+static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   if (!ctx || !d) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   freeScene(ctx);
@@ -615,7 +668,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
     if (ce == hipSuccess)
       rc = it.builder == SRT_BUILDER_PLOC
                ? srt_ploc_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
-                                dt.base, envInt("SRT_PLOC_RADIUS", 64), &depth)
+                                dt.base, ctx->tun.plocRadius, &depth)
                : srt_lbvh_build(&s, dRefs, it.count, it.time0, it.time1, const_cast<float4*>(s.nodes), const_cast<uint8_t*>(s.nodeAxis),
                                 dt.base, &depth);
     (void)hipFree(dRefs);
@@ -630,7 +683,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
   s.numTris = d->numTriangles;
   s.numSpheres = d->numSpheres;
   // fastDiv's operand certificate for the box coordinates (srt_kernels.hip): 0 or 2^-77 <= |c| <= 2^30
-  s.fastDivScene = envInt("SRT_FAST_DIV", 1);
+  s.fastDivScene = ctx->tun.fastDiv;
   for (const float4& v : nodes)
     for (float c : {v.x, v.y, v.z}) {
       float ac = fabsf(c);
@@ -642,7 +695,7 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) {
 }
 
 // Host-only: build world item `item` exactly as srtUploadScene does, without a device.
-int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) {
+static int srtBuildBvhImpl(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) {
   if (!d || !count) return 1;
   if (validateScene(nullptr, d)) return 1;
   if (item < 0 || item >= d->numWorld || d->world[item].kind != SRT_WORLD_BVH) return fail(nullptr, "srtBuildBvh: item %d is not a bvh", item);
@@ -662,7 +715,7 @@ int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t ca
   return 0;
 }
 
-int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) {
+static int srtGetBvhImpl(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) {
   if (!ctx || !count) return 1;
   if (item < 0 || item >= (int32_t)ctx->itemNodes.size()) return fail(ctx, "srtGetBvh: item %d out of range", item);
   if (ctx->itemDeviceTree[item].base >= 0 && ctx->itemNodes[item].empty()) {
@@ -733,7 +786,7 @@ static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   return 0;
 }
 
-int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) {
+static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) {
   if (!ctx || !p || !dAccumTiles) return 1;
   if (checkParams(ctx, p)) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));
@@ -745,7 +798,7 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   a.imageWidth = p->imageWidth;
   a.imageHeight = p->imageHeight;
   a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
-  a.tileBlock = std::max(1, envInt("SRT_TILE_BLOCK", SRT_TILE_BLOCK));
+  a.tileBlock = std::max(1, ctx->tun.tileBlock);
   a.numTiles = srtNumTiles(p->imageWidth, p->imageHeight);
   a.spp = p->spp;
   a.maxBounce = p->maxBounce;
@@ -765,14 +818,14 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
     int unit = 8;
     const int unitsAt8 = (a.numLocalTiles + 7) / 8;
     if (unitsAt8 >= 2 * 12 * SRT_MAX_QUEUES) unit = 8 * pow2Floor(unitsAt8 / (12 * SRT_MAX_QUEUES));
-    a.unitTiles = std::min(1024, std::max(1, envInt("SRT_UNIT_TILES", unit)));
+    a.unitTiles = std::min(1024, std::max(1, ctx->tun.unitTiles > 0 ? ctx->tun.unitTiles : unit));
     const int units = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
     // ... and only while every wave still gets a few dozen groups: with few groups per wave (16 spp on a
     // 10 M-triangle soup: 14 400 groups for 5 120 waves) one counter balances better than stealing does.
     const int64_t groups = (int64_t)a.numLocalTiles * a.sppChunks, waves = (int64_t)ctx->prop.multiProcessorCount * 20;
     const int byUnits = pow2Floor(std::max(1, units / 12));
     const int byGroups = pow2Floor((int)std::max<int64_t>(1, std::min<int64_t>(SRT_MAX_QUEUES, groups / (2 * waves))));
-    a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, envInt("SRT_QUEUES", std::min(byUnits, byGroups))));
+    a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, ctx->tun.queues > 0 ? ctx->tun.queues : std::min(byUnits, byGroups)));
   }
   {
     // work items and output slots are indexed with 32-bit integers in the kernel (queue counters run over
@@ -787,11 +840,11 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
   }
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
-  a.shadeMin = envInt("SRT_SHADE_MIN", 16);
-  a.primMin = envInt("SRT_PRIM_MIN", 12);
-  a.hitMin = envInt("SRT_HIT_MIN", 24);
-  a.fuseMin = envInt("SRT_FUSE_MIN", 32);
-  a.nodeBurst = std::max(1, envInt("SRT_NODE_BURST", 32));
+  a.shadeMin = ctx->tun.shadeMin;
+  a.primMin = ctx->tun.primMin;
+  a.hitMin = ctx->tun.hitMin;
+  a.fuseMin = ctx->tun.fuseMin;
+  a.nodeBurst = std::max(1, ctx->tun.nodeBurst);
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
@@ -838,7 +891,7 @@ int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGath
   a.imageWidth = p->imageWidth;
   a.imageHeight = p->imageHeight;
   a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
-  a.tileBlock = std::max(1, envInt("SRT_TILE_BLOCK", SRT_TILE_BLOCK));
+  a.tileBlock = std::max(1, ctx->tun.tileBlock);
   a.tileStride = p->tileStride < 1 ? 1 : p->tileStride;
   a.numLocalTiles = srtNumLocalTiles(p->imageWidth, p->imageHeight, a.tileStride);
   a.spp = p->spp;
@@ -863,7 +916,7 @@ int srtRenderImage(SrtContext* ctx, const SrtRenderParams* pIn, float* hAccum, u
     if (hipMalloc(&dTiles, tileBytes) != hipSuccess) { fail(ctx, "hipMalloc tiles"); break; }
     if (hRgba && hipMalloc(&dRgba, nPix * 4) != hipSuccess) { fail(ctx, "hipMalloc rgba"); break; }
     if (hAccum && hipMalloc(&dAcc, nPix * sizeof(float4)) != hipSuccess) { fail(ctx, "hipMalloc accum"); break; }
-    if (srtRenderTiles(ctx, &p, dTiles, nullptr)) break;
+    if (srtRenderTilesImpl(ctx, &p, dTiles, nullptr)) break;
     if (srtResolveTiles(ctx, &p, dTiles, dRgba, dAcc, nullptr)) break;
     if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "render kernel failed: %s", hipGetErrorString(hipGetLastError())); break; }
     if (hRgba && hipMemcpy(hRgba, dRgba, nPix * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "copy rgba"); break; }
@@ -931,7 +984,7 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
 }
 
 // design probe: traversal-only throughput on a caller-supplied ray set (single-root scenes, static spheres)
-int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) {
+static int srtTraverseBenchImpl(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) {
   if (!ctx || !rays || n < 1 || reps < 1 || !msOut) return 1;
   if (!ctx->haveScene) return fail(ctx, "travbench: no scene uploaded");
   HIP_OK(ctx, hipSetDevice(ctx->device));
@@ -1039,6 +1092,42 @@ int srtDeviceInfo(SrtContext* ctx, char* name, int32_t nameCap, int32_t* numCUs,
   if (numCUs) *numCUs = ctx->prop.multiProcessorCount;
   if (clockMHz) *clockMHz = ctx->prop.clockRate / 1000;
   return 0;
+}
+
+
+// No exception crosses the C boundary (std::vector / std::string allocations above may throw).
+#define SRT_GUARDED(ctx, call)                                                  \
+  try {                                                                         \
+    return (call);                                                              \
+  } catch (const std::exception& e) {                                           \
+    return fail(ctx, "%s: %s", __func__, e.what());                             \
+  } catch (...) {                                                               \
+    return fail(ctx, "%s: unknown exception", __func__);                        \
+  }
+int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) { SRT_GUARDED(ctx, srtUploadSceneImpl(ctx, d)); }
+int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) { SRT_GUARDED(nullptr, srtBuildBvhImpl(d, item, out, capacity, count, stackDepth)); }
+int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) { SRT_GUARDED(ctx, srtGetBvhImpl(ctx, item, nodes, capacity, count)); }
+int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) { SRT_GUARDED(ctx, srtRenderTilesImpl(ctx, p, dAccumTiles, streamPtr)); }
+int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) { SRT_GUARDED(ctx, srtTraverseBenchImpl(ctx, rays, n, reps, msOut, tOut, refOut)); }
+
+/* include/srt_hip_test.h: per-context diagnostic tunables */
+int srtSetTunable(SrtContext* ctx, const char* name, int32_t value) {
+  if (!ctx || !name) return 1;
+  for (const TunableName& t : kTunables)
+    if (!strcmp(t.name, name)) {
+      ctx->tun.*(t.field) = value;
+      return 0;
+    }
+  return fail(ctx, "srtSetTunable: unknown tunable '%s'", name);
+}
+int srtGetTunable(SrtContext* ctx, const char* name, int32_t* value) {
+  if (!ctx || !name || !value) return 1;
+  for (const TunableName& t : kTunables)
+    if (!strcmp(t.name, name)) {
+      *value = ctx->tun.*(t.field);
+      return 0;
+    }
+  return fail(ctx, "srtGetTunable: unknown tunable '%s'", name);
 }
 
 }  // extern "C"

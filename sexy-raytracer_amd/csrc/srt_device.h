@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/srt_hip.h"
+#include "../../include/srt_hip_test.h"
 
 // Child / world reference encoding on the device:
 //   ref >= 0          BVH node index

@@ -20,8 +20,10 @@ lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
            "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks",
-           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterTest", "srtDivTest", "srtTraverseBench",
+           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
+# include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
+TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtTraverseBench", "srtSetTunable", "srtGetTunable"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -50,6 +52,8 @@ lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
 lib.srtTraverseBench.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp, _vp]
+lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
+lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
 lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -190,6 +194,15 @@ class Context:
         ref = np.zeros(len(rays), np.int32)
         self._check(lib.srtTraverseBench(self.h, rays.ctypes.data, len(rays), reps, C.byref(ms), t.ctypes.data, ref.ctypes.data))
         return ms.value, t, ref
+
+    def set_tunable(self, name, value):
+        """Diagnostic knobs of the work distribution / wave scheduler (include/srt_hip_test.h)."""
+        self._check(lib.srtSetTunable(self.h, name.encode(), int(value)))
+
+    def get_tunable(self, name):
+        v = C.c_int32(0)
+        self._check(lib.srtGetTunable(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

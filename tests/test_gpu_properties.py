@@ -96,7 +96,7 @@ def test_sample_sum_linearity(ctx, abi, srt, camera):
     assert abs(other[..., :3].mean() - seq[..., :3].mean()) < 0.01 * seq[..., :3].mean()
 
 
-def test_image_independent_of_work_distribution(ctx, abi, srt, camera, monkeypatch):
+def test_image_independent_of_work_distribution(ctx, abi, srt, camera):
     """The tile order, the number of work queues and the unit size decide only WHO renders WHAT WHEN
     (csrc/srt_kernels.hip "work queues"): the image must not change, also when every queue has to be
     stolen from (more queues than units) and for frames that are not a whole number of tiles/blocks."""
@@ -104,17 +104,18 @@ def test_image_independent_of_work_distribution(ctx, abi, srt, camera, monkeypat
     ctx.set_camera(camera)
     for (w, h, spp) in ((203, 117, 48), (64, 8, 70)):
         p = abi.default_render_params(w, h, spp, 4, seed=11, spp_chunks=0)
-        for var in ("SRT_QUEUES", "SRT_UNIT_TILES", "SRT_TILE_BLOCK"):
-            monkeypatch.delenv(var, raising=False)
+        defaults = {k: ctx.get_tunable(k) for k in ("queues", "unit_tiles", "tile_block")}
         want, want_rgba = ctx.render_image(p)
         assert (want[..., 3] == spp).all()
         for queues, unit, block in ((1, 8, 8), (64, 1, 8), (64, 16, 8), (7, 3, 5), (8, 8, 1), (64, 1024, 16)):
-            monkeypatch.setenv("SRT_QUEUES", str(queues))
-            monkeypatch.setenv("SRT_UNIT_TILES", str(unit))
-            monkeypatch.setenv("SRT_TILE_BLOCK", str(block))
+            ctx.set_tunable("queues", queues)
+            ctx.set_tunable("unit_tiles", unit)
+            ctx.set_tunable("tile_block", block)
             got, got_rgba = ctx.render_image(p)
             assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), (queues, unit, block)
             assert np.array_equal(got_rgba, want_rgba)
+        for k, v in defaults.items():
+            ctx.set_tunable(k, v)
 
 
 def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):

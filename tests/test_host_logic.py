@@ -18,6 +18,11 @@ def test_abi_exports_every_declared_symbol(dev):
     missing = [n for n in sorted(declared) if not hasattr(dev.lib, n)]
     assert not missing, missing
     assert declared == set(dev.EXPORTS)
+    # the test hooks live in their own header, outside the drop-in boundary
+    test_header = open(os.path.join(ROOT, "include", "srt_hip_test.h")).read()
+    hooks = set(re.findall(r"\b(srt[A-Z]\w*)\s*\(", test_header))
+    assert hooks == set(dev.TEST_EXPORTS) and not (hooks & declared)
+    assert not [n for n in sorted(hooks) if not hasattr(dev.lib, n)]
 
 
 def test_abi_struct_sizes(abi):

@@ -11,6 +11,7 @@ abi, dev = srt.abi, srt.device()
 
 
 ctx = None
+TUN = {}  # diagnostic tunables applied to the context (srtSetTunable)
 
 
 def main():
@@ -22,6 +23,8 @@ def main():
         ctx = dev.Context(0)
         ctx.upload_scene(srt.scenes.SCENES[scene]())
         ctx.set_camera(dev.make_camera(abi.default_camera_params()))
+    for k, v in TUN.items():
+        ctx.set_tunable(k, v)
     ranks = [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]
     one = None
     for n in ranks:
@@ -36,7 +39,7 @@ def main():
                     ctx.render_tiles(p, local.data_ptr(), None)
                 best = min(best, ctx.last_kernel_ms())
             ms.append(round(best, 3))
-        print(json.dumps({"unit_tiles": os.environ.get("SRT_UNIT_TILES", "default"), "queues": os.environ.get("SRT_QUEUES", "default"), "tile_block": os.environ.get("SRT_TILE_BLOCK", "default"), "ranks": n, "frame": [W, H, spp], "kernel_ms": ms, "max_ms": max(ms),
+        print(json.dumps({"unit_tiles": TUN.get("unit_tiles", "default"), "queues": TUN.get("queues", "default"), "tile_block": TUN.get("tile_block", "default"), "ranks": n, "frame": [W, H, spp], "kernel_ms": ms, "max_ms": max(ms),
                           "partition_efficiency": round(sum(ms) / n / max(ms), 4),
                           "vs_one_rank": None if n == 1 or one is None else round(one / (n * max(ms)), 4)}), flush=True)
         if n == 1:
@@ -45,11 +48,11 @@ def main():
 
 for nq in os.environ.get("QUEUES", "").split(","):
     if nq:
-        os.environ["SRT_QUEUES"] = nq
+        TUN["queues"] = int(nq)
     for blk in os.environ.get("BLOCKS", "").split(","):
         if blk:
-            os.environ["SRT_TILE_BLOCK"] = blk
+            TUN["tile_block"] = int(blk)
         for ut in os.environ.get("UNITS", "").split(","):
             if ut:
-                os.environ["SRT_UNIT_TILES"] = ut
+                TUN["unit_tiles"] = int(ut)
             main()

@@ -29,8 +29,8 @@ def main():
             "burst": [int(x) for x in os.environ.get("SWEEP_BURST", "16").split(",")],
             "hit": [int(x) for x in os.environ.get("SWEEP_HIT", "24").split(",")]}
     for c, sm, pm, nb, hm in itertools.product(grid["chunks"], grid["shade"], grid["prim"], grid["burst"], grid["hit"]):
-        os.environ["SRT_SHADE_MIN"], os.environ["SRT_PRIM_MIN"], os.environ["SRT_NODE_BURST"] = str(sm), str(pm), str(nb)
-        os.environ["SRT_HIT_MIN"] = str(hm)
+        for k, v in (("shade_min", sm), ("prim_min", pm), ("node_burst", nb), ("hit_min", hm)):
+            ctx.set_tunable(k, v)
         print("chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d : %8.1f Msamples/s" % (c, sm, pm, nb, hm, run(c)), flush=True)
 
 main()

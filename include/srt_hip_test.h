@@ -25,12 +25,10 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
  * plain IEEE division on count operand pairs.  HOST pointers. */
 int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
 
-/* Design probe (not part of the render path): throughput of a traversal-only kernel (the render kernel's
- * node / primitive steps with lanes pulling rays from an array) on a caller-supplied ray set, processed
- * `reps` times.  Single-root scenes with static spheres.  msOut = kernel time; tOut/refOut (optional, n
- * entries) = hit distance and device primitive reference per ray. */
-int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut,
-                     int32_t* refOut);
+/* Sub-step profile of the most recent countStats launch (shader clocks summed over waves, diagnostics only):
+ * out10 = { hit step: hit record, textures, direction draw, BRDF + bookkeeping; restart step;
+ *           hit-step executions, hit-step lanes, restart-step executions, restart-step lanes, reserved }. */
+int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10);
 
 /* Per-context diagnostic tunables of the work distribution and the wave scheduler ("queues", "unit_tiles",
  * "tile_block", "shade_min", "prim_min", "hit_min", "fuse_min", "node_burst", "ploc_radius", "fast_div",

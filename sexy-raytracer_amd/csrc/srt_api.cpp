@@ -32,9 +32,6 @@ int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0,
 int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                    uint8_t* outAxis, int base, int radius, int* depthOut);
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
-int srt_launch_travbench(const DevScene* sc, const float4* rays, float2* out, int32_t* queue, int n, int reps, float tMin,
-                         int primMin, int fetchMin, int nodeBurst, unsigned long long* stats, int grid, size_t ldsBytes,
-                         hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
 }
@@ -417,7 +414,7 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   HIP_OK(ctx, hipSetDevice(deviceOrdinal));
   HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
   HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, SRT_MAX_QUEUES * 16 * sizeof(int32_t)));
-  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 18 * sizeof(unsigned long long)));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 32 * sizeof(unsigned long long)));
   HIP_OK(ctx, hipEventCreate(&ctx->evStart));
   HIP_OK(ctx, hipEventCreate(&ctx->evStop));
   *out = ctx;
@@ -562,7 +559,7 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       nodeAxis.resize(nodeAxis.size() + cnt, 3);
       ctx->itemDeviceTree.back().base = base;
       ctx->itemDeviceTree.back().count = cnt;
-      world.push_back(base);
+      world.push_back(SRT_NODE_REF(base));
       continue;
     }
     Builder b;
@@ -577,8 +574,8 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       memcpy(o.bmax, n.box.mx, 12);
       o.left = n.left;
       o.right = n.right;
-      int32_t l = n.left >= 0 ? n.left + base : devRef(n.left);
-      int32_t r = n.right >= 0 ? n.right + base : devRef(n.right);
+      int32_t l = n.left >= 0 ? SRT_NODE_REF(n.left + base) : devRef(n.left);
+      int32_t r = n.right >= 0 ? SRT_NODE_REF(n.right + base) : devRef(n.right);
       float lf, rf;
       memcpy(&lf, &l, 4);
       memcpy(&rf, &r, 4);
@@ -586,7 +583,7 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       nodes.push_back(make_float4(n.box.mx[0], n.box.mx[1], n.box.mx[2], rf));
       nodeAxis.push_back(n.axis);
     }
-    world.push_back(base);
+    world.push_back(SRT_NODE_REF(base));
     stackDepth = std::max(stackDepth, b.maxPending);
     // tree depth for reporting: longest root->node chain
     std::vector<int> depth(b.nodes.size(), 1);
@@ -621,17 +618,37 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
     if (m.type == SRT_MAT_PBR) uv = uv || readsUv(m.normalTex) || readsUv(m.metallicTex) || readsUv(m.roughnessTex);
     o.flags = (uv ? 1 : 0) | ((m.type == SRT_MAT_PBR && m.normalTex >= 0) ? 2 : 0);
   }
+  // textures: 3-byte images are padded to one aligned dword per texel, so a lookup is one
+  // buffer_load_dword; 1- and 2-byte images keep their byte rows (the 1-bpp quirk of texture.h:147 reads the
+  // neighbouring texels)
   std::vector<DevTexture> texs(d->numTextures);
+  std::vector<uint8_t> texels;
   for (int i = 0; i < d->numTextures; ++i) {
     const SrtTextureIn& t = d->textures[i];
     DevTexture& o = texs[i];
     memset(&o, 0, sizeof o);
-    o.kind = t.kind; o.width = t.width; o.height = t.height; o.bpp = t.bpp; o.offset = t.texelOffset;
+    o.kind = t.kind; o.width = t.width; o.height = t.height; o.bpp = t.bpp;
     o.even = t.even; o.odd = t.odd;
     memcpy(o.color, t.color, 12);
+    if (t.kind != SRT_TEX_IMAGE || t.width == 0) continue;
+    const size_t n = (size_t)t.width * t.height;
+    const uint8_t* src = d->texels + t.texelOffset;
+    texels.resize((texels.size() + 3) & ~(size_t)3);  // dword aligned
+    o.offset = (int64_t)texels.size();
+    if (t.bpp == 3) {
+      const size_t at = texels.size();
+      texels.resize(at + 4 * n);
+      for (size_t k = 0; k < n; ++k) {
+        texels[at + 4 * k + 0] = src[3 * k + 0];
+        texels[at + 4 * k + 1] = src[3 * k + 1];
+        texels[at + 4 * k + 2] = src[3 * k + 2];
+        texels[at + 4 * k + 3] = 255;
+      }
+    } else {
+      texels.insert(texels.end(), src, src + n * t.bpp);
+    }
+    if (texels.size() > (size_t)0x7fffff00) return fail(ctx, "scene: more than 2 GiB of texels");
   }
-  std::vector<uint8_t> texels(d->texels, d->texels + d->numTexelBytes);
-
   DevScene& s = ctx->scene;
   memset(&s, 0, sizeof s);
   if (uploadVec(ctx, nodeAxis, &s.nodeAxis, 64) || uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
@@ -679,6 +696,8 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   s.numWorld = (int32_t)world.size();
   s.stackDepth = stackDepth;
   const bool lbvhOk = lbvhCertificate;
+  if (nodes.size() / 2 > (size_t)SRT_MAX_NODES) return fail(ctx, "scene: %zu BVH nodes exceed the %d the device references can address", nodes.size() / 2, SRT_MAX_NODES);
+  s.texelBytes = (int32_t)texels.size();
   s.numNodes = (int32_t)(nodes.size() / 2);
   s.numTris = d->numTriangles;
   s.numSpheres = d->numSpheres;
@@ -728,7 +747,7 @@ static int srtGetBvhImpl(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32
     auto conv = [&](float bits) -> int32_t {
       int32_t r;
       memcpy(&r, &bits, 4);
-      if (r >= 0) return r - dt.base;
+      if (r >= 0) return SRT_NODE_INDEX(r) - dt.base;
       int32_t pr = ~r;
       return ~((pr & 1) ? ctx->hostSphPrimId[pr >> 1] : ctx->hostTriPrimId[pr >> 1]);
     };
@@ -868,7 +887,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
-  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 18 * sizeof(unsigned long long), stream));
+  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
   int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -983,63 +1002,6 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
   return rc;
 }
 
-// design probe: traversal-only throughput on a caller-supplied ray set (single-root scenes, static spheres)
-static int srtTraverseBenchImpl(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) {
-  if (!ctx || !rays || n < 1 || reps < 1 || !msOut) return 1;
-  if (!ctx->haveScene) return fail(ctx, "travbench: no scene uploaded");
-  HIP_OK(ctx, hipSetDevice(ctx->device));
-  std::vector<float4> packed((size_t)n * 2);
-  for (int i = 0; i < n; ++i) {
-    packed[2 * (size_t)i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], rays[i].time);
-    packed[2 * (size_t)i + 1] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], 0.0f);
-  }
-  float4* dRays = nullptr;
-  float2* dOut = nullptr;
-  const bool profile = envInt("SRT_TB_PROFILE", 0) != 0;
-  const size_t lds = (size_t)(ctx->scene.stackDepth + 1) * 256 * sizeof(int32_t);
-  const int grid = ctx->prop.multiProcessorCount * envInt("SRT_TB_BLOCKS", 8);
-  hipError_t e = hipSuccess;
-  do {
-    if ((e = hipMalloc((void**)&dRays, packed.size() * sizeof(float4))) != hipSuccess) break;
-    if ((e = hipMalloc((void**)&dOut, (size_t)n * sizeof(float2))) != hipSuccess) break;
-    if ((e = hipMemcpy(dRays, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) break;
-    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {  // warm-up, then timed
-      if ((e = hipMemset(ctx->dQueue, 0, 2 * sizeof(int32_t))) != hipSuccess) break;
-      if ((e = hipMemset(ctx->dStats, 0, 18 * sizeof(unsigned long long))) != hipSuccess) break;
-      if ((e = hipEventRecord(ctx->evStart, nullptr)) != hipSuccess) break;
-      e = (hipError_t)srt_launch_travbench(&ctx->scene, dRays, dOut, ctx->dQueue, n, reps, 0.001f, envInt("SRT_PRIM_MIN", 12),
-                                           envInt("SRT_FETCH_MIN", 32), envInt("SRT_NODE_BURST", 16),
-                                           profile ? ctx->dStats : nullptr, grid, lds, nullptr);
-      if (e != hipSuccess) break;
-      if ((e = hipEventRecord(ctx->evStop, nullptr)) != hipSuccess) break;
-      if ((e = hipEventSynchronize(ctx->evStop)) != hipSuccess) break;
-      e = hipEventElapsedTime(msOut, ctx->evStart, ctx->evStop);
-    }
-    if (e != hipSuccess) break;
-    if (tOut && refOut) {
-      std::vector<float2> h(n);
-      if ((e = hipMemcpy(h.data(), dOut, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost)) != hipSuccess) break;
-      for (int i = 0; i < n; ++i) {
-        tOut[i] = h[i].x;
-        memcpy(&refOut[i], &h[i].y, 4);
-      }
-    }
-    if (profile) {
-      unsigned long long v[9];
-      if ((e = hipMemcpy(v, ctx->dStats, sizeof v, hipMemcpyDeviceToHost)) != hipSuccess) break;
-      const char* names[3] = {"node", "prim", "fetch"};
-      for (int k = 0; k < 3; ++k)
-        fprintf(stderr, "travbench %-5s: %12llu executions, mean fill %5.1f lanes, %8.1f clocks/execution, %5.1f%% of step time\n",
-                names[k], v[3 + k], v[3 + k] ? (double)v[6 + k] / v[3 + k] : 0.0, v[3 + k] ? (double)v[k] / v[3 + k] : 0.0,
-                100.0 * v[k] / (double)(v[0] + v[1] + v[2] + 1));
-    }
-  } while (0);
-  if (dRays) (void)hipFree(dRays);
-  if (dOut) (void)hipFree(dOut);
-  if (e != hipSuccess) return fail(ctx, "travbench failed: %s", hipGetErrorString(e));
-  return 0;
-}
-
 // test entry: the slab test's reciprocal-based division against the plain IEEE division
 int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow) {
   if (!ctx || !n || !d || !outFast || !outSlow || count < 1) return 1;
@@ -1108,7 +1070,15 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) { SRT_GUARDED(ctx, sr
 int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) { SRT_GUARDED(nullptr, srtBuildBvhImpl(d, item, out, capacity, count, stackDepth)); }
 int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) { SRT_GUARDED(ctx, srtGetBvhImpl(ctx, item, nodes, capacity, count)); }
 int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) { SRT_GUARDED(ctx, srtRenderTilesImpl(ctx, p, dAccumTiles, streamPtr)); }
-int srtTraverseBench(SrtContext* ctx, const SrtRay* rays, int32_t n, int32_t reps, float* msOut, float* tOut, int32_t* refOut) { SRT_GUARDED(ctx, srtTraverseBenchImpl(ctx, rays, n, reps, msOut, tOut, refOut)); }
+
+/* include/srt_hip_test.h: sub-step profile of the counting variant's last launch */
+int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10) {
+  if (!ctx || !out10) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  HIP_OK(ctx, hipDeviceSynchronize());
+  HIP_OK(ctx, hipMemcpy(out10, ctx->dStats + 18, 10 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
 
 /* include/srt_hip_test.h: per-context diagnostic tunables */
 int srtSetTunable(SrtContext* ctx, const char* name, int32_t value) {

@@ -13,10 +13,14 @@
 #include "../../include/srt_hip_test.h"
 
 // Child / world reference encoding on the device:
-//   ref >= 0          BVH node index
+//   ref >= 0          BVH node: the BYTE OFFSET of its record in `nodes` (index * 32), so that a visit needs no
+//                     address arithmetic; SRT_NODE_REF / SRT_NODE_INDEX convert
 //   ref <  0          primitive: r = ~ref, (r & 1) = 1 sphere / 0 triangle, r >> 1 = index
 //   SRT_REF_DONE      traversal sentinel (never a valid primitive)
 #define SRT_REF_DONE ((int32_t)0x80000000)
+#define SRT_NODE_REF(index) ((int32_t)(index) << 5)
+#define SRT_NODE_INDEX(ref) ((int32_t)(ref) >> 5)
+#define SRT_MAX_NODES (1 << 26) /* byte offsets stay below 2^31 */
 #define SRT_MAX_QUEUES 64
 
 struct DevMaterial {  // 48 B
@@ -30,14 +34,14 @@ struct DevMaterial {  // 48 B
 struct DevTexture {  // 48 B
   int32_t kind;
   int32_t width, height, bpp;
-  int64_t offset;  // byte offset into texels
+  int64_t offset;  // byte offset into texels (< 2^31); 3-byte images are stored 4 bytes per texel
   int32_t even, odd;
   float color[3];
   int32_t pad;
 };
 
 struct DevScene {
-  // 2 x float4 per node: (bmin.xyz, left) (bmax.xyz, right)      -- 32 B / node visit
+  // 2 x float4 per node: (bmin.xyz, left) (bmax.xyz, right), children as references (above)  -- 32 B / node visit
   const float4* nodes;
   // 3 x float4 per triangle: (v0.xyz, n.x) (v1.xyz, n.y) (v2.xyz, n.z), n = (v1-v0)x(v2-v0)  -- 48 B / test
   const float4* triTest;
@@ -58,7 +62,8 @@ struct DevScene {
   int32_t fastDivScene;  // 1: every box coordinate is 0 or in [2^-77, 2^30] (see fastDiv in srt_kernels.hip)
   const DevMaterial* materials;
   const DevTexture* textures;
-  const uint8_t* texels;  // zero padded by >= 16 bytes
+  const uint8_t* texels;  // images of >= 3 bytes per pixel as one dword per texel (RGBA8), others as byte rows
+  int32_t texelBytes;     // extent of `texels` (buffer-resource bound: reads past it return 0)
 };
 
 struct DevCamera {

@@ -215,13 +215,17 @@ __device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V
   return !(tMax <= tMin);
 }
 
-// Slab test decided from one-multiply quotients with an error certificate.
-// q' = n * r1 is within 1.8e-7 (relative) of the correctly rounded n / d the reference computes
-// (r1 within 1 ulp of 1/d, one rounding in the product; operands certified normal by rayFast).
-// min/max preserve a relative bound: |max_i x_i - max_i x'_i| <= eps*|max_i x'_i| when every
-// |x_i - x'_i| <= eps*|x'_i| (tMin and the running closest t are exact), so the approximate interval
-// ends tMinA, tMaxA are within eps of the exact ones and the reference's decision (tMax <= tMin ->
-// miss) is certain whenever |tMaxA - tMinA| > eps*(|tMaxA| + |tMinA|), eps = 2^-21 (2.6x the bound).
+// Slab test decided from one-FMA quotients with an error certificate.
+// The reference computes a = fl(fl(n - o) / d) per plane (aabb.h:14-17).  With r = refinedRcp(d) (within
+// 3u of 1/d, u = 2^-24) and m = fl(-o * r), both per ray, A = fma(n, r, m) satisfies
+//   |A - a| <= 6.2u |A| + 1.03u |o/d|            (one rounding each in r, m, the fma and the reference's
+//                                                  subtraction and division; operands certified normal)
+// i.e. a relative part and an absolute part K <= 2^-23 M, M = max_k |m_k|.  x -> x +- (eps|x| + K) is
+// monotone, so min/max carry the bound through: the approximate interval ends tMinA, tMaxA are within
+// eps|t| + K of the reference's (tMin and the running closest t are exact), and the reference's decision
+// (tMax <= tMin -> miss) is certain whenever |tMaxA - tMinA| > eps (|tMaxA| + |tMinA|) + 2K with
+// eps = 2^-21 (1.3x the bound).  tolAbs = 2K = 2^-22 M per ray, or +inf for a ray outside fastDiv's
+// operand ranges (every visit of such a ray is "undecided" and takes the IEEE divisions).
 // Returns the approximate verdict and whether it is uncertain (the caller then runs the exact test).
 // The min/max chain is written with the hardware instructions directly: fminf/fmaxf make the compiler
 // quiet possible signalling NaNs first (a `v_max_f32 x, x` per live-in operand per visit), which buys
@@ -253,16 +257,26 @@ __device__ __forceinline__ float hwMaxUniform(float a, float b) {
   asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
   return r;
 }
-__device__ __forceinline__ bool boxHitApprox(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax, bool& undecided) {
-  const float ax = (n0.x - r.o.x) * r1.x, bx = (n1.x - r.o.x) * r1.x;
-  const float ay = (n0.y - r.o.y) * r1.y, by = (n1.y - r.o.y) * r1.y;
-  const float az = (n0.z - r.o.z) * r1.z, bz = (n1.z - r.o.z) * r1.z;
-  tMin = hwMaxUniform(hwMax3(hwMin(ax, bx), hwMin(ay, by), hwMin(az, bz)), tMin);
+// UNIFORM_TMIN: tMin is wave-uniform (a kernel argument) and is read from its scalar register
+template <bool UNIFORM_TMIN>
+__device__ __forceinline__ bool boxHitApprox(float4 n0, float4 n1, V3 r1, V3 m, float tolAbs, float tMin, float tMax,
+                                             bool& undecided) {
+  const float ax = __builtin_fmaf(n0.x, r1.x, m.x), bx = __builtin_fmaf(n1.x, r1.x, m.x);
+  const float ay = __builtin_fmaf(n0.y, r1.y, m.y), by = __builtin_fmaf(n1.y, r1.y, m.y);
+  const float az = __builtin_fmaf(n0.z, r1.z, m.z), bz = __builtin_fmaf(n1.z, r1.z, m.z);
+  const float lo = hwMax3(hwMin(ax, bx), hwMin(ay, by), hwMin(az, bz));
+  tMin = UNIFORM_TMIN ? hwMaxUniform(lo, tMin) : hwMax(lo, tMin);
   tMax = hwMin(hwMin3(hwMax(ax, bx), hwMax(ay, by), hwMax(az, bz)), tMax);
   const float diff = tMax - tMin;
-  const float tol = 0x1p-21f * (fabsf(tMax) + fabsf(tMin));
-  undecided = !(fabsf(diff) > tol);  // also when a NaN got in
+  const float tol = __builtin_fmaf(0x1p-21f, fabsf(tMax) + fabsf(tMin), tolAbs);
+  undecided = !(fabsf(diff) > tol);  // also when a NaN got in, and always when tolAbs = +inf
   return diff > tol;
+}
+// per ray: m = fl(-o * r) and the absolute part of the certificate's tolerance
+__device__ __forceinline__ void slabSetup(const V3& o, const V3& r1, bool certified, V3& m, float& tolAbs) {
+  m = mk(-(o.x * r1.x), -(o.y * r1.y), -(o.z * r1.z));
+  const float M = fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fabsf(m.z));
+  tolAbs = certified ? 0x1p-22f * M : SRT_INF;
 }
 
 // sphere.h:47-52
@@ -335,6 +349,13 @@ template <bool CLOSEST, bool COUNT>
 __device__ __forceinline__ int traverse(const DevScene& sc, const Ray& r, float tMin, float tMax, int32_t* stack,
                                         float& tHit, Counters& cnt) {
   const float a = lenSq(r.d);  // sphere.h:56, per ray
+  // the render kernel's slab test: certified one-FMA decision, IEEE divisions when it cannot decide
+  const bool certified = sc.fastDivScene != 0 && fastDivOperandOk(r.o.x, r.d.x) && fastDivOperandOk(r.o.y, r.d.y) &&
+                         fastDivOperandOk(r.o.z, r.d.z);
+  const V3 rcpD = mk(refinedRcp(r.d.x), refinedRcp(r.d.y), refinedRcp(r.d.z));
+  V3 negOR;
+  float slabTol;
+  slabSetup(r.o, rcpD, certified, negOR, slabTol);
   float closest = tMax;
   int hitRef = SRT_REF_DONE;
   for (int w = 0; w < sc.numWorld; ++w) {
@@ -342,13 +363,17 @@ __device__ __forceinline__ int traverse(const DevScene& sc, const Ray& r, float 
     int sp = 0;
     while (true) {
       while (cur >= 0) {
-        float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+        const float4* node = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes) + cur);  // byte offset
+        float4 n0 = node[0], n1 = node[1];
         if (COUNT) cnt.nodeVisits++;
-        if (boxHit(n0, n1, r, tMin, closest)) {
+        bool undecided;
+        bool hitBox = boxHitApprox<false>(n0, n1, rcpD, negOR, slabTol, tMin, closest, undecided);
+        if (undecided) hitBox = boxHit(n0, n1, r, tMin, closest);
+        if (hitBox) {
           if (COUNT) cnt.boxPasses++;
           int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
           if (CLOSEST) {  // near child first (see the render kernel's node step)
-            const int axis = sc.nodeAxis[cur];
+            const int axis = sc.nodeAxis[cur >> 5];
             const float dAxis = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
             if (axis < 3 && dAxis < 0.0f) {
               const int tmp = left;
@@ -468,8 +493,14 @@ __device__ __forceinline__ void triRecord(const DevScene& sc, int idx, const Ray
 }
 
 // ------------------------------------------------------------------ textures (texture.h)
+// Texel storage (srt_api.cpp): images of 3 or 4 bytes per pixel are kept as one aligned dword per texel
+// (RGB padded to RGBA8), fetched with ONE buffer_load_dword; 1- and 2-byte images keep the reference's
+// byte rows, because texture.h:147 reads pixel[1] and pixel[2] of a 1-bpp image from the NEXT texels (and
+// past the end of the buffer at the last texel: reads as 0 here and in the oracle -- raw buffer loads
+// return 0 out of range).  DevTexture::offset is a byte offset into the texel buffer (< 2^31).
+typedef __amdgpu_buffer_rsrc_t Rsrc;
 template <bool COUNT>
-__device__ __forceinline__ V3 texLeaf(const DevScene& sc, int id, float u, float v, uint32_t& fetches) {
+__device__ __forceinline__ V3 texLeaf(const DevScene& sc, Rsrc rsTexels, int id, float u, float v, uint32_t& fetches) {
   const DevTexture& t = sc.textures[id];
   if (t.kind == SRT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);  // texture.h:26-28
   // imagePNG::value, texture.h:129-148
@@ -483,36 +514,56 @@ __device__ __forceinline__ V3 texLeaf(const DevScene& sc, int id, float u, float
   if (!(v == v)) j = 0;
   if (i >= t.width) i = t.width - 1;
   if (j >= t.height) j = t.height - 1;
-  const uint8_t* px = sc.texels + t.offset + (int64_t)j * (t.bpp * t.width) + (int64_t)i * t.bpp;
-  return mk((float)px[0], (float)px[1], (float)px[2]);  // bpp==1: the next two texels (texture.h:147)
+  const int texel = j * t.width + i;
+  if (t.bpp >= 3) {
+    const uint32_t px = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, (int)t.offset + 4 * texel, 0, 0);
+    return mk((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu));
+  }
+  const int at = (int)t.offset + t.bpp * texel;  // bpp == 1: the next two texels (texture.h:147)
+  return mk((float)__builtin_amdgcn_raw_buffer_load_b8(rsTexels, at, 0, 0), (float)__builtin_amdgcn_raw_buffer_load_b8(rsTexels, at + 1, 0, 0),
+            (float)__builtin_amdgcn_raw_buffer_load_b8(rsTexels, at + 2, 0, 0));
+}
+
+// floor(x / pi) and the distance of x / pi to the integers, in float-float arithmetic: q = x * (ih + il)
+// with ih + il = 1/pi to 2^-51, carried as an unevaluated sum (two FMAs recover the product's rounding
+// error), so that for |q| < 2^22 the fraction is known to 3e-8.  Returns false when x / pi is within 1e-6
+// of an integer, zero, huge or not finite.
+__device__ __forceinline__ bool piPeriods(float x, int& periods) {
+  const float ih = 0x1.45f306p-2f, il = 0x1.b9391p-27f;
+  const float qh = x * ih;
+  const float ql = __builtin_fmaf(x, il, __builtin_fmaf(x, ih, -qh));
+  float f = floorf(qh);
+  float r = (qh - f) + ql;  // qh - f is exact
+  const bool below = r < 0.0f, above = r >= 1.0f;
+  f = below ? f - 1.0f : (above ? f + 1.0f : f);
+  r = below ? r + 1.0f : (above ? r - 1.0f : r);
+  periods = (int)f;
+  return r > 1e-6f && r < 1.0f - 1e-6f && fabsf(qh) < 4194304.0f;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ V3 texValue(const DevScene& sc, int id, float u, float v, V3 p, uint32_t& fetches) {
+__device__ __forceinline__ V3 texValue(const DevScene& sc, Rsrc rsTexels, int id, float u, float v, V3 p, uint32_t& fetches) {
   const DevTexture& t = sc.textures[id];
   if (t.kind == SRT_TEX_CHECKER) {  // texture.h:42-48
     // Only the sign of sinf(10x)*sinf(10y)*sinf(10z) is used.  sin(a) is negative exactly when
-    // floor(a/pi) is odd; a float is never close enough to a multiple of pi for sinf to lose the sign,
-    // so the three range reductions below replace three sinf calls.  Arguments within 1e-6 of a
-    // multiple of pi (in units of pi), zero and non-finite ones take the reference's expression.
+    // floor(a/pi) is odd, and with a/pi at least 1e-6 away from the integers every sine is at least 3e-6
+    // in magnitude: sinf cannot lose its sign and the product cannot underflow, so three range
+    // reductions replace three sinf calls.  Arguments that close to a multiple of pi, zero, huge and
+    // non-finite ones take the reference's expression.
     const float ax = 10.0f * p.x, ay = 10.0f * p.y, az = 10.0f * p.z;
-    const double qx = (double)ax * 0.31830988618379067, qy = (double)ay * 0.31830988618379067,
-                 qz = (double)az * 0.31830988618379067;
-    const double fx = floor(qx), fy = floor(qy), fz = floor(qz);
-    const double rx = qx - fx, ry = qy - fy, rz = qz - fz;
-    const bool clear = rx > 1e-6 && rx < 1.0 - 1e-6 && ry > 1e-6 && ry < 1.0 - 1e-6 && rz > 1e-6 && rz < 1.0 - 1e-6 &&
-                       fabs(qx) < 1e9 && fabs(qy) < 1e9 && fabs(qz) < 1e9;
+    int kx, ky, kz;
+    const bool cx = piPeriods(ax, kx), cy = piPeriods(ay, ky), cz = piPeriods(az, kz);
     bool negative;
-    if (clear) {
-      negative = ((((long long)fx) ^ ((long long)fy) ^ ((long long)fz)) & 1) != 0;
+    if (cx && cy && cz) {
+      negative = ((kx ^ ky ^ kz) & 1) != 0;
     } else {
       float sines = sinf(ax) * sinf(ay) * sinf(az);
       negative = sines < 0;
     }
     int child = negative ? t.odd : t.even;
-    return texLeaf<COUNT>(sc, child, u, v, fetches) * 255.0f;
+    return texLeaf<COUNT>(sc, rsTexels, child, u, v, fetches) * 255.0f;
   }
-  return texLeaf<COUNT>(sc, id, u, v, fetches);
+  return texLeaf<COUNT>(sc, rsTexels, id, u, v, fetches);
 }
 
 // ------------------------------------------------------------------ pbr.h
@@ -532,15 +583,15 @@ __device__ __forceinline__ float schlickGAF(float NdotV, float roughness) {  // 
 // ------------------------------------------------------------------ materials
 // returns false when the path ends here (scatter == false); emitted is always set.
 template <bool COUNT>
-__device__ __forceinline__ bool shade(const DevScene& sc, const Ray& rIn, const Record& rec, Pcg& rng, V3& att,
-                                      Ray& out, V3& emitted, uint32_t& fetches) {
+__device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const Ray& rIn, const Record& rec, Pcg& rng, V3& att,
+                                      Ray& out, V3& emitted, uint32_t& fetches, unsigned long long* stamp = nullptr) {
   const DevMaterial& m = sc.materials[rec.material];
   emitted = mk(0.0f, 0.0f, 0.0f);  // material.h:18-20
   out.o = rec.p;
   out.time = rIn.time;
   switch (m.type) {
     case SRT_MAT_LIGHT: {  // material.h:144-150
-      emitted = texValue<COUNT>(sc, m.albedoTex, rec.u, rec.v, rec.p, fetches);
+      emitted = texValue<COUNT>(sc, rsTexels, m.albedoTex, rec.u, rec.v, rec.p, fetches);
       return false;
     }
     case SRT_MAT_METAL: {  // material.h:91-97
@@ -581,12 +632,12 @@ __device__ __forceinline__ bool shade(const DevScene& sc, const Ray& rIn, const 
     default: {  // pbrMetallicRoughness::scatter, material.h:156-245
       V3 a0;
       if (m.albedoTex >= 0)
-        a0 = texValue<COUNT>(sc, m.albedoTex, rec.u, rec.v, rec.p, fetches) / 255.0f;
+        a0 = texValue<COUNT>(sc, rsTexels, m.albedoTex, rec.u, rec.v, rec.p, fetches) / 255.0f;
       else
         a0 = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
       V3 normal;
       if (m.normalTex >= 0) {
-        V3 nt = texValue<COUNT>(sc, m.normalTex, rec.u, rec.v, rec.p, fetches);
+        V3 nt = texValue<COUNT>(sc, rsTexels, m.normalTex, rec.u, rec.v, rec.p, fetches);
         nt = mk(nt.x - 128.0f, nt.y - 128.0f, nt.z - 128.0f) / 128.0f;  // vec3.h:103-110
         // Matrix3f(T|B|N) * nt, each row reduced x + (y + z)
         V3 w = mk(rec.tangent.x * nt.x + (rec.bitangent.x * nt.y + rec.normal.x * nt.z),
@@ -597,15 +648,17 @@ __device__ __forceinline__ bool shade(const DevScene& sc, const Ray& rIn, const 
         normal = rec.normal;
       float mt, rg;
       if (m.metallicTex >= 0)
-        mt = clampf(texValue<COUNT>(sc, m.metallicTex, rec.u, rec.v, rec.p, fetches).x / 255.0f, 0.0f, 1.0f);
+        mt = clampf(texValue<COUNT>(sc, rsTexels, m.metallicTex, rec.u, rec.v, rec.p, fetches).x / 255.0f, 0.0f, 1.0f);
       else
         mt = m.metalness;
       if (m.roughnessTex >= 0)
-        rg = clampf(texValue<COUNT>(sc, m.roughnessTex, rec.u, rec.v, rec.p, fetches).y / 255.0f, 0.0f, 1.0f);
+        rg = clampf(texValue<COUNT>(sc, rsTexels, m.roughnessTex, rec.u, rec.v, rec.p, fetches).y / 255.0f, 0.0f, 1.0f);
       else
         rg = m.roughness;
 
+      if (COUNT && stamp) stamp[0] = clock64();  // textures done
       V3 sd = normal + unitv(rng.inUnitSphere());  // randomUnitVector, vec3.h:72-74
+      if (COUNT && stamp) stamp[1] = clock64();  // direction drawn
       // nearZero (vec3.h:49-52): float |x| compared against the DOUBLE 1e-8
       if ((double)fabsf(sd.x) < 1e-8 && (double)fabsf(sd.y) < 1e-8 && (double)fabsf(sd.z) < 1e-8) sd = normal;
       sd = unitv(sd);
@@ -674,7 +727,6 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // one is a spare for the node step's unconditional store), then 3*maxBounce attenuation floats and 3
   // floats of terminal radiance
   int32_t* const stackBase = lds + threadIdx.x;
-  int32_t* const stackTop = stackBase + a.scene.stackDepth * SRT_BLOCK;  // highest slot that may be live
   *stackBase = SRT_REF_DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
   float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * SRT_BLOCK + threadIdx.x);
   const int lane = threadIdx.x & 63;
@@ -684,11 +736,15 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
   const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
+  const __amdgpu_buffer_rsrc_t rsTexels = makeRsrc(sc.texels, sc.texelBytes);
   const bool singleRoot = SINGLE || sc.numWorld == 1;
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
   // scheduler profile (COUNT variant only; wave-uniform)
   unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
+  // sub-step profile of the two shading kinds (COUNT variant; wave-uniform clocks): hit step = record /
+  // textures / direction draw / BRDF + bookkeeping; restart step; executions and lanes of each kind
+  unsigned long long pSub[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long pStart = COUNT ? clock64() : 0;
 
   // ---- work queues.  The local tiles (in tile order) are cut into units of unitTiles tiles, dealt
@@ -730,8 +786,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   auto atHit = [&]() { return cur == SRT_REF_DONE && hitRef != SRT_REF_DONE; };
   auto atRestart = [&]() { return cur == SRT_REF_DONE && hitRef == SRT_REF_DONE && alive; };
   float closest = SRT_INF, rayA = 0.0f;
-  V3 rcpD = mk(0.0f, 0.0f, 0.0f);  // refined reciprocals of ray.d (fastDiv)
-  bool rayFast = false;
+  // slab test per ray (boxHitApprox): refined reciprocals of ray.d, m = -o * rcpD, absolute tolerance
+  V3 rcpD = mk(0.0f, 0.0f, 0.0f), negOR = mk(0.0f, 0.0f, 0.0f);
+  float slabTol = SRT_INF;
   int dirNeg = 0;  // CLOSEST: sign bits of ray.d, for the near-child-first order
 
   // next pending reference after the current subtree is done; ends the traversal when none is left.
@@ -749,9 +806,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   auto startTraversal = [&]() {
     if (COUNT) cRays++;
     rayA = lenSq(ray.d);  // sphere.h:56
-    rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
-              fastDivOperandOk(ray.o.z, ray.d.z);
+    const bool certified = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
+                           fastDivOperandOk(ray.o.z, ray.d.z);
     rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
+    slabSetup(ray.o, rcpD, certified, negOR, slabTol);
     if (CLOSEST) dirNeg = (ray.d.x < 0.0f ? 1 : 0) | (ray.d.y < 0.0f ? 2 : 0) | (ray.d.z < 0.0f ? 4 : 0);
     closest = SRT_INF;
     hitRef = SRT_REF_DONE;
@@ -841,15 +899,20 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             pLanes[M_NODE] += __popcll(__ballot(atNode()));
           }
           if (atNode()) {
-            float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
-            const int axis = CLOSEST ? sc.nodeAxis[cur] : 3;  // issued with the node record, used after the box test
+            float4 n0 = bufLoad4(rsNodes, cur), n1 = bufLoad4(rsNodes, cur + 16);  // node references are byte offsets
+            const int axis = CLOSEST ? sc.nodeAxis[cur >> 5] : 3;  // issued with the node record, used after the box test
             const int top = *sptr;  // pending reference, or the sentinel: read while the node record is on its way
+#if defined(SRT_PROBE_LOAD128)
+            const u32x4 probe = __builtin_amdgcn_raw_buffer_load_b128(rsNodes, cur + 32, 0, 0);  // timing probe: one more 16-B load
+#elif defined(SRT_PROBE_LOAD32)
+            const uint32_t probe = __builtin_amdgcn_raw_buffer_load_b32(rsNodes, cur + 32, 0, 0);  // timing probe: one more 4-B load
+#endif
             if (COUNT) cNodes++;
-            // certified one-multiply test for every lane (its value is ignored for uncertified rays); the few
-            // lanes it cannot decide, and rays outside fastDiv's operand ranges, take the IEEE divisions
+            // certified one-FMA test for every lane; the few visits it cannot decide, and every visit of a ray
+            // outside fastDiv's operand ranges (slabTol = inf), take the IEEE divisions
             bool undecided;
-            bool hitBox = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest, undecided);
-            if (!rayFast || undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+            bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
+            if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
             if (COUNT && hitBox) cBox++;
             // descend left and leave right pending, or take the next pending reference (selects, see popNext)
             int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
@@ -865,11 +928,23 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             }
             sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
             // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
-            // miss: take the pending reference
+            // miss: take the pending reference.  The stack cannot overflow: its capacity (stackDepth slots + a
+            // spare) is the tree's maximum number of pending references, computed or verified at upload.
             int move = hitBox ? (right != left ? 1 : 0) : -1;  // slots; selects of inline constants
             asm("" : "+v"(move));  // keep it in slots: folded into bytes it needs two literal moves per visit
+#if defined(SRT_PROBE_LOAD128)
+            if (probe.x == 0x7fc12345u) move = 0;  // never true for a box coordinate; keeps the probe load alive
+#elif defined(SRT_PROBE_LOAD32)
+            if (probe == 0x7fc12345u) move = 0;
+#elif defined(SRT_PROBE_VALU)
+            {  // timing probe: eight dependent VALU instructions more per visit
+              float pv = closest;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pv));
+              if (__float_as_uint(pv) == 0x7fc12345u) move = 0;
+            }
+#endif
             sptr += move * SRT_BLOCK;  // one shift-add
-            sptr = sptr < stackTop ? sptr : stackTop;  // capacity is guaranteed at upload; never index LDS beyond it regardless
             cur = hitBox ? left : top;
             if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
               cur = sc.world[w];
@@ -884,6 +959,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
     } else if (pick == M_HIT) {
       // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
+      const unsigned long long h0 = COUNT ? clock64() : 0;
+      unsigned long long hStamp[2] = {h0, h0}, h1 = h0;
+      if (COUNT) {
+        pSub[5]++;
+        pSub[6] += nH;
+      }
       if (atHit()) {
         Record rec;
         int pr = ~hitRef;
@@ -895,7 +976,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         Ray next;
         uint32_t fetches = 0;
         if (COUNT && rec.isTri) cShTri++;
-        bool scattered = shade<COUNT>(sc, ray, rec, rng, att, next, emitted, fetches);
+        if (COUNT) h1 = clock64();
+        bool scattered = shade<COUNT>(sc, rsTexels, ray, rec, rng, att, next, emitted, fetches, COUNT ? hStamp : nullptr);
         if (COUNT) cTex += fetches;
         V3 terminal = emitted;  // main.cpp:46-47
         bool done = true;
@@ -920,9 +1002,31 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           startTraversal();
         }
       }
+      if (COUNT) {
+        // stamps are per lane; lanes that skipped a section keep the previous stamp: take the wave maximum
+        unsigned long long t1 = h1, t2 = hStamp[0], t3 = hStamp[1];
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long o1 = __shfl_xor(t1, off), o2 = __shfl_xor(t2, off), o3 = __shfl_xor(t3, off);
+          t1 = o1 > t1 ? o1 : t1;
+          t2 = o2 > t2 ? o2 : t2;
+          t3 = o3 > t3 ? o3 : t3;
+        }
+        const unsigned long long h4 = clock64();
+        t2 = t2 < t1 ? t1 : t2;
+        t3 = t3 < t2 ? t2 : t3;
+        pSub[0] += t1 - h0;
+        pSub[1] += t2 - t1;
+        pSub[2] += t3 - t2;
+        pSub[3] += h4 - t3;
+      }
     } else if (pick == M_SHADE) {
       // ------------------------------------------------ path restart: miss / path end (main.cpp:39-40,49-51),
       // pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
+      const unsigned long long r0 = COUNT ? clock64() : 0;
+      if (COUNT) {
+        pSub[7]++;
+        pSub[8] += nS;
+      }
       if (atRestart()) {
         if (pend != 0) {
           V3 L = background;  // main.cpp:39-40
@@ -1020,6 +1124,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         }
         // else: exit, or an empty item (pixel outside the image): stays in M_SHADE and pulls again
       }
+      if (COUNT) pSub[4] += clock64() - r0;
     }
     if (COUNT) pCyc[pk] += clock64() - pT0;
   }
@@ -1038,6 +1143,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         atomicAdd(&a.stats[15 + k], pLanes[k]);
       }
       atomicAdd(&a.stats[11], (unsigned long long)(clock64() - pStart));
+      for (int k = 0; k < 10; ++k) atomicAdd(&a.stats[18 + k], pSub[k]);
     }
   }
 }
@@ -1157,159 +1263,13 @@ __global__ void srt_scatter_kernel(const ScatterArgs a) {
   Ray out;
   out.d = mk(0, 0, 0);
   uint32_t fetches = 0;
-  bool ok = shade<false>(a.scene, r, rec, rng, att, out, em, fetches);
+  bool ok = shade<false>(a.scene, makeRsrc(a.scene.texels, a.scene.texelBytes), r, rec, rng, att, out, em, fetches);
   float* o = a.out + 13 * i;
   o[0] = att.x; o[1] = att.y; o[2] = att.z;
   o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z;
   o[6] = out.o.x; o[7] = out.o.y; o[8] = out.o.z;
   o[9] = ok ? 1.0f : 0.0f;
   o[10] = em.x; o[11] = em.y; o[12] = em.z;
-}
-
-// =================================================================== traversal-only throughput probe
-// Design experiment (srtTraverseBench): the render kernel's node / primitive steps alone, lanes pulling
-// rays from an array with a wave-aggregated counter, results (t, ref) written per ray.  Small register
-// footprint -> up to 8 waves/SIMD.  Answers "how many rays/s would a traversal-only kernel of a
-// wavefront (traverse / shade split) design reach?" before such a design is built.
-struct TravBenchArgs {
-  DevScene scene;
-  const float4* rays;  // 2 x float4 per ray: (o.xyz, time) (d.xyz, -)
-  float2* out;         // (t, ref bits) per ray
-  int32_t* queue;
-  int32_t n, reps;
-  float tMin;
-  int32_t primMin, fetchMin, nodeBurst;
-  unsigned long long* stats;  // 9 slots: cycles[3], executions[3], lanes[3] per step kind (node, prim, fetch)
-};
-
-__global__ __launch_bounds__(SRT_BLOCK, 8) void srt_travbench_kernel(const TravBenchArgs a) {
-  unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
-  extern __shared__ int32_t lds[];
-  int32_t* stack = lds + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const DevScene& sc = a.scene;
-  const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
-  const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
-  const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
-  enum { T_NODE = 0, T_PRIM = 1, T_FETCH = 2, T_EXIT = 3 };
-  int mode = T_FETCH;
-  int rayIdx = -1;
-  long long batchPos = 0, batchEnd = 0;
-  Ray ray;
-  ray.o = ray.d = mk(0, 0, 0);
-  ray.time = 0;
-  int cur = SRT_REF_DONE, sp = 0, hitRef = SRT_REF_DONE;
-  float closest = SRT_INF, rayA = 0;
-  V3 rcpD = mk(0, 0, 0);
-  bool rayFast = false;
-  const long long total = (long long)a.n * a.reps;
-  for (;;) {
-    const int nN = __popcll(__ballot(mode == T_NODE)), nP = __popcll(__ballot(mode == T_PRIM)),
-              nF = __popcll(__ballot(mode == T_FETCH));
-    if ((nN | nP | nF) == 0) break;
-    int pick = (nF >= a.fetchMin || (nN | nP) == 0) ? T_FETCH : ((nP >= a.primMin || nN == 0) ? T_PRIM : T_NODE);
-    pick = __builtin_amdgcn_readfirstlane(pick);
-    const unsigned long long pT0 = a.stats ? clock64() : 0;
-    if (a.stats && pick != T_NODE) {
-      pSteps[pick]++;
-      pLanes[pick] += pick == T_PRIM ? nP : nF;
-    }
-    if (pick == T_NODE) {
-      const int keep = nN - (nN >> 2);
-      int budget = a.nodeBurst;
-      do {
-        if (a.stats) {
-          pSteps[0]++;
-          pLanes[0] += __popcll(__ballot(mode == T_NODE));
-        }
-        if (mode == T_NODE) {
-          float4 n0 = bufLoad4(rsNodes, cur * 32), n1 = bufLoad4(rsNodes, cur * 32 + 16);
-          bool hitBox;
-          if (rayFast) {
-            bool undecided;
-            hitBox = boxHitApprox(n0, n1, ray, rcpD, a.tMin, closest, undecided);
-            if (undecided) hitBox = boxHitFast(n0, n1, ray, rcpD, a.tMin, closest);
-          } else {
-            hitBox = boxHit(n0, n1, ray, a.tMin, closest);
-          }
-          const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-          const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
-          stack[sp * SRT_BLOCK] = right;
-          const bool push = hitBox && right != left, pop = !hitBox && sp > 0, exhausted = !hitBox && sp == 0;
-          sp += (push ? 1 : 0) - (pop ? 1 : 0);
-          sp = min(sp, sc.stackDepth);
-          cur = hitBox ? left : top;
-          if (exhausted) cur = SRT_REF_DONE;
-          mode = cur == SRT_REF_DONE ? T_FETCH : (cur >= 0 ? T_NODE : T_PRIM);
-        }
-      } while (--budget > 0 && __popcll(__ballot(mode == T_NODE)) >= keep);
-    } else if (pick == T_PRIM) {
-      if (mode == T_PRIM) {
-        int pr = ~cur;
-        float t;
-        bool ok;
-        if (pr & 1) {
-          const int off = (pr >> 1) * 48;
-          float4 q0 = bufLoad4(rsSpheres, off);
-          ok = sphereHitV(mk(q0.x, q0.y, q0.z), q0.w, ray, rayA, a.tMin, closest, t);
-        } else {
-          const int off = (pr >> 1) * 48;
-          ok = triHitV<false>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray, a.tMin,
-                              closest, t);
-        }
-        if (ok) {
-          closest = t;
-          hitRef = cur;
-        }
-        const int top = stack[(sp > 0 ? sp - 1 : 0) * SRT_BLOCK];
-        const bool havePending = sp > 0;
-        sp -= havePending ? 1 : 0;
-        cur = havePending ? top : SRT_REF_DONE;
-        mode = cur == SRT_REF_DONE ? T_FETCH : (cur >= 0 ? T_NODE : T_PRIM);
-      }
-    } else {
-      if (mode == T_FETCH) {
-        if (rayIdx >= 0) a.out[rayIdx] = make_float2(closest, __int_as_float(hitRef));
-        // lanes claim rays in batches of 16 (one global counter saturates near 90 M atomics/s)
-        if (batchPos >= batchEnd) {
-          const unsigned long long mF = __ballot(1);
-          const int leader = __ffsll((long long)mF) - 1;
-          long long base = 0;
-          if (lane == leader) base = (long long)atomicAdd((unsigned long long*)a.queue, (unsigned long long)__popcll(mF) * 16ull);
-          base = __shfl(base, leader);
-          batchPos = base + 16ll * __popcll(mF & ((1ull << lane) - 1ull));
-          batchEnd = batchPos + 16;
-        }
-        const long long idx = batchPos++;
-        if (idx >= total) {
-          mode = T_EXIT;
-          rayIdx = -1;
-        } else {
-          rayIdx = (int)(idx % a.n);
-          float4 r0 = a.rays[2 * (size_t)rayIdx], r1 = a.rays[2 * (size_t)rayIdx + 1];
-          ray.o = mk(r0.x, r0.y, r0.z);
-          ray.time = r0.w;
-          ray.d = mk(r1.x, r1.y, r1.z);
-          rayA = lenSq(ray.d);
-          rayFast = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
-                    fastDivOperandOk(ray.o.z, ray.d.z);
-          rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
-          closest = SRT_INF;
-          hitRef = SRT_REF_DONE;
-          sp = 0;
-          cur = sc.world[0];
-          mode = cur >= 0 ? T_NODE : T_PRIM;
-        }
-      }
-    }
-    if (a.stats) pCyc[pick] += clock64() - pT0;
-  }
-  if (a.stats && lane == 0)
-    for (int k = 0; k < 3; ++k) {
-      atomicAdd(&a.stats[k], pCyc[k]);
-      atomicAdd(&a.stats[3 + k], pSteps[k]);
-      atomicAdd(&a.stats[6 + k], pLanes[k]);
-    }
 }
 
 // fastDiv vs the compiler's IEEE division on arbitrary operand arrays (srtDivTest)
@@ -1323,14 +1283,6 @@ __global__ void srt_divtest_kernel(const float* n, const float* d, float* fast, 
 
 // =================================================================== launch wrappers (host)
 extern "C" {
-
-int srt_launch_travbench(const DevScene* sc, const float4* rays, float2* out, int32_t* queue, int n, int reps, float tMin,
-                         int primMin, int fetchMin, int nodeBurst, unsigned long long* stats, int grid, size_t ldsBytes,
-                         hipStream_t stream) {
-  TravBenchArgs a{*sc, rays, out, queue, n, reps, tMin, primMin, fetchMin, nodeBurst, stats};
-  hipLaunchKernelGGL(srt_travbench_kernel, dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, a);
-  return (int)hipGetLastError();
-}
 
 int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream) {
   hipLaunchKernelGGL(srt_divtest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, n, d, fast, slow, count);

@@ -175,7 +175,7 @@ __global__ void lbvhFit(const int* left, const int* right, const int* parentInte
     if (lc >= 0) {
       mnL = nodeMin[lc];
       mxL = nodeMax[lc];
-      lref = lc + base;
+      lref = SRT_NODE_REF(lc + base);
     } else {
       int p = sortedVals[~lc];
       mnL = boxMin[p];
@@ -185,7 +185,7 @@ __global__ void lbvhFit(const int* left, const int* right, const int* parentInte
     if (rc >= 0) {
       mnR = nodeMin[rc];
       mxR = nodeMax[rc];
-      rref = rc + base;
+      rref = SRT_NODE_REF(rc + base);
     } else {
       int p = sortedVals[~rc];
       mnR = boxMin[p];
@@ -377,7 +377,7 @@ __global__ void plocMerge(const PlocCluster* c, const int* nn, const unsigned lo
     outNodes[2 * (size_t)(base + node) + 1] = make_float4(mx.x, mx.y, mx.z, r.w);
     outAxis[base + node] = (uint8_t)axis;
     const int depth = max(__float_as_int(me.mx.w), __float_as_int(other.mx.w)) + 1;
-    me.mn = make_float4(mn.x, mn.y, mn.z, __int_as_float(base + node));
+    me.mn = make_float4(mn.x, mn.y, mn.z, __int_as_float(SRT_NODE_REF(base + node)));
     me.mx = make_float4(mx.x, mx.y, mx.z, __int_as_float(depth));
   }
   next[pos] = me;

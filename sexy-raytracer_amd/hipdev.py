@@ -11,6 +11,8 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsrt_hip.so")
+if os.environ.get("SRT_HIP_LIB"):  # measurement tools only: an experimental build of the same library
+    LIB_PATH = os.path.abspath(os.environ["SRT_HIP_LIB"])
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("HIP extension not built: %s is missing (run __graft_entry__.build() or "
@@ -23,7 +25,7 @@ EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostR
            "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtTraverseBench", "srtSetTunable", "srtGetTunable"]
+TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -51,9 +53,10 @@ lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
-lib.srtTraverseBench.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_float), _vp, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
+if hasattr(lib, "srtGetShadeProfile"):
+    lib.srtGetShadeProfile.argtypes = [_vp, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
 lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -187,14 +190,6 @@ class Context:
         self._check(lib.srtDivTest(self.h, n.ctypes.data, d.ctypes.data, len(n), fast.ctypes.data, slow.ctypes.data))
         return fast, slow
 
-    def traverse_bench(self, rays, reps=1):
-        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
-        ms = C.c_float(0)
-        t = np.zeros(len(rays), np.float32)
-        ref = np.zeros(len(rays), np.int32)
-        self._check(lib.srtTraverseBench(self.h, rays.ctypes.data, len(rays), reps, C.byref(ms), t.ctypes.data, ref.ctypes.data))
-        return ms.value, t, ref
-
     def set_tunable(self, name, value):
         """Diagnostic knobs of the work distribution / wave scheduler (include/srt_hip_test.h)."""
         self._check(lib.srtSetTunable(self.h, name.encode(), int(value)))
@@ -203,6 +198,11 @@ class Context:
         v = C.c_int32(0)
         self._check(lib.srtGetTunable(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def shade_profile(self):
+        out = np.zeros(10, np.uint64)
+        self._check(lib.srtGetShadeProfile(self.h, out.ctypes.data))
+        return [int(x) for x in out]
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

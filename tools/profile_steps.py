@@ -25,3 +25,9 @@ for k, n in (("Node", "nodeVisits"), ("Prim", None), ("Shade", "rays")):
 sched = tot - st["cyclesNode"] - st["cyclesPrim"] - st["cyclesShade"]
 print("sched: %5.1f%% of wave time" % (100.0 * sched / tot))
 print({k: st[k] for k in ("samples", "rays", "nodeVisits", "triTests", "sphereTests")})
+if hasattr(dev.lib, "srtGetShadeProfile"):
+    sp = ctx.shade_profile()
+    hit_tot = sum(sp[0:4])
+    print("hit step   : %d executions, mean fill %.1f lanes, %.0f clocks each: record %.0f%%, textures %.0f%%, direction draw %.0f%%, BRDF+rest %.0f%%" % (
+        sp[5], sp[6] / max(1, sp[5]), hit_tot / max(1, sp[5]), *(100.0 * x / max(1, hit_tot) for x in sp[0:4])))
+    print("restart    : %d executions, mean fill %.1f lanes, %.0f clocks each" % (sp[7], sp[8] / max(1, sp[7]), sp[4] / max(1, sp[7])))

@@ -4,8 +4,9 @@
   metric   Msamples/s (W x H x spp / s), 720p masterchief scene @ 5000 spp, 4 bounces
            (BASELINE.json configs[3]; main.cpp:175-180).
   step     one full render of that frame: every rank renders its interleaved 8x8 tiles
-           (srtRenderTiles), one gather of the tile buffers to rank 0 (RCCL, N>1 only),
-           rank 0 resolves to RGBA8 (srtResolveTiles).  Scene and camera are resident in HBM
+           (srtRenderTiles), one gather of the tile buffers to rank 0 (N>1 only: srtGatherTiles, the
+           library's own ncclGather call over RCCL, on the render's stream), rank 0 resolves to RGBA8
+           (srtResolveTiles).  Scene and camera are resident in HBM
            before the timed region; the output stays on the device.
   N GPUs   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
            strong scaling: the frame is fixed, tiles shard across ranks.
@@ -94,9 +95,9 @@ def build_scene(srt, scene_name, builder):
 
 
 def gather_tiles(local, rank, world):
-    """One gather of equal-sized tile buffers to rank 0.  local: (numLocalTiles, 64, 4).
-    Returns (world, numLocalTiles, 64, 4) on rank 0, None elsewhere.  Backend-agnostic (nccl = RCCL
-    on the GPU box, gloo in the CPU tests)."""
+    """torch.distributed form of the one gather, used by the CPU tests (gloo) and by rehearsals
+    of N ranks on one GPU; on RCCL the bench calls the library's own srtGatherTiles instead (main()).
+    local: (numLocalTiles, 64, 4).  Returns (world, numLocalTiles, 64, 4) on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -404,12 +405,26 @@ def main():
                                        spp_chunks=chunks if args.spp_chunks > 0 else 0, traversal=trav)  # 0 = library plan
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms = []
+    native_gather = world > 1 and backend == "nccl"
+    gathered_buf = None
+    if native_gather:
+        # the C-ABI's own communicator: rank 0 makes the id, torch.distributed (already up for the barrier
+        # and the timing reduction) only carries its 128 bytes to the other ranks
+        box = [dev.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], world, rank)
+        if rank == 0:
+            gathered_buf = torch.empty((world, nloc, 64, 4), dtype=torch.float32, device="cuda")
 
     def step(record):
         ctx.render_tiles(params, local.data_ptr(), stream)
         if record:
             kernel_ms.append(ctx.last_kernel_ms())  # HIP events on the launch stream, around the render kernel
-        gathered = gather_tiles(local, rank, world)
+        if native_gather:
+            ctx.gather_tiles(params, local.data_ptr(), gathered_buf.data_ptr() if rank == 0 else None, stream)
+            gathered = gathered_buf
+        else:
+            gathered = gather_tiles(local, rank, world)
         if rank == 0:
             ctx.resolve_tiles(params, gathered.data_ptr(), rgba.data_ptr(), None, stream)
 
@@ -472,7 +487,8 @@ def main():
                        "max_bounce": max_bounce, "seed": args.seed, "spp_chunks": chunks,
                        "tree": builder, "traversal": "faithful (bvh.h order)" if traversal == "faithful" else "closest hit (not the parity path)",
                        "scene_build_upload_s": round(t_build, 2),
-                       "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather" % world},
+                       "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather (%s)" % (
+                           world, "srtGatherTiles: ncclGather" if native_gather else ("none" if world == 1 else "torch.distributed " + backend))},
             "device": info,
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),

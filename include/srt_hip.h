@@ -279,6 +279,26 @@ int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles,
 int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGatheredTiles,
                     void* dRgba, void* dAccumImage, void* stream);
 
+/* Multi-GPU: one process per GPU, the scene replicated, rank r of N renders tile positions
+ * r, r+N, ... (SrtRenderParams.tileFirst / tileStride), and the path's only collective is ONE gather of the
+ * ranks' equal-sized tile buffers to rank 0 over RCCL (ncclGather), after which rank 0 calls
+ * srtResolveTiles.  The reference is single-device (gl.h:28-31); these entries extend its device seam.
+ *   srtCommGetUniqueId  rank 0: 128 opaque bytes (an ncclUniqueId) to hand to the other ranks by the host
+ *                       program's own means (file, MPI, a launcher's key-value store)
+ *   srtCommInit         every rank: joins the communicator (collective: returns when all ranks have)
+ *   srtGatherTiles      every rank: dLocalTiles = float4[numLocalTiles*64] (DEVICE); rank 0 also passes
+ *                       dGathered = float4[numRanks][numLocalTiles*64] (DEVICE), others NULL.
+ *                       Asynchronous on `stream`.  With one rank it degenerates to a device copy.
+ *   srtRenderImageRanks the blocking main.cpp:182-227 form across the ranks (collective): render own tiles,
+ *                       the one gather, rank 0 resolves into its caller-owned HOST buffers
+ *   srtCommDestroy      also done by srtDestroy */
+#define SRT_COMM_ID_BYTES 128
+int srtCommGetUniqueId(void* id128);
+int srtCommInit(SrtContext* ctx, const void* id128, int32_t numRanks, int32_t rank);
+int srtGatherTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dLocalTiles, void* dGathered, void* stream);
+int srtRenderImageRanks(SrtContext* ctx, const SrtRenderParams* p, float* hAccum, uint8_t* hRgba);
+int srtCommDestroy(SrtContext* ctx);
+
 /* Blocking convenience with caller-owned HOST buffers: the main.cpp:182,224
  * `target` contract.  hAccum (float[W*H*4]) and hRgba (uint8[W*H*4]) may be NULL. */
 int srtRenderImage(SrtContext* ctx, const SrtRenderParams* p, float* hAccum, uint8_t* hRgba);

@@ -25,6 +25,21 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
  * plain IEEE division on count operand pairs.  HOST pointers. */
 int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
 
+/* Per-ray view into the RENDER kernel's own traversal (not srtTraceRays' kernel): renders sample
+ * p->sampleFirst of every pixel with the counting variant of srt_render_kernel and records, per pixel, the
+ * ray that path traced at bounce `depth` (0 = the camera ray) and what the kernel's node / primitive steps
+ * made of it.  Feeding the recorded rays to the oracle's world.hit() checks the render kernel's slab-test
+ * certificate, stack handling and step scheduler ray by ray.  hOut: W*H records in image order. */
+typedef struct SrtAovRecord {
+  float o[3], d[3], time; /* the ray (tMin = p->tMin, tMax = +inf, main.cpp:39) */
+  int32_t valid;          /* 0: the pixel's path ended before this bounce */
+  int32_t prim;           /* index into prims[], SRT_NO_HIT on a miss */
+  float t;
+  int32_t nodeVisits, boxPasses, triTests, sphereTests;
+  int32_t pad[2];
+} SrtAovRecord;
+int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAovRecord* hOut);
+
 /* Sub-step profile of the most recent countStats launch (shader clocks summed over waves, diagnostics only):
  * out10 = { hit step: hit record, textures, direction draw, BRDF + bookkeeping; restart step;
  *           hit-step executions, hit-step lanes, restart-step executions, restart-step lanes, reserved }. */

@@ -103,6 +103,9 @@ HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("normal",
                       ("tangent", "<f4", 3), ("bitangent", "<f4", 3), ("uv", "<f4", 2),
                       ("frontFace", "<i4"), ("material", "<i4"), ("nodeVisits", "<i4"),
                       ("boxPasses", "<i4"), ("triTests", "<i4"), ("sphereTests", "<i4")])
+AOV_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("time", "<f4"), ("valid", "<i4"), ("prim", "<i4"), ("t", "<f4"),
+                      ("nodeVisits", "<i4"), ("boxPasses", "<i4"), ("triTests", "<i4"), ("sphereTests", "<i4"), ("pad", "<i4", 2)])
+assert AOV_DTYPE.itemsize == 64
 NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("left", "<i4"), ("bmax", "<f4", 3), ("right", "<i4")])
 assert RAY_DTYPE.itemsize == C.sizeof(SrtRay)
 assert HIT_DTYPE.itemsize == C.sizeof(SrtHit)

@@ -247,6 +247,10 @@ struct SrtContext {
   // work areas
   int32_t* dQueue = nullptr;
   unsigned long long* dStats = nullptr;
+  void* comm = nullptr;          // ncclComm_t (srt_comm.cpp)
+  int commRanks[2] = {1, 0};     // number of ranks, this rank
+  SrtAovRecord* dAov = nullptr;  // set only for the duration of srtRenderAov
+  int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
@@ -421,9 +425,17 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   return 0;
 }
 
+// srt_comm.cpp's view of the context
+int srtCtxFail(SrtContext* ctx, const char* text) { return fail(ctx, "%s", text); }
+int srtCtxDevice(const SrtContext* ctx) { return ctx->device; }
+void** srtCtxCommSlot(SrtContext* ctx) { return &ctx->comm; }
+int* srtCtxCommRanks(SrtContext* ctx) { return ctx->commRanks; }
+int srtCommDestroy(SrtContext* ctx);
+
 int srtDestroy(SrtContext* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
+  (void)srtCommDestroy(ctx);
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
@@ -866,6 +878,8 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.nodeBurst = std::max(1, ctx->tun.nodeBurst);
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
+  a.aov = p->countStats ? ctx->dAov : nullptr;
+  a.aovDepth = ctx->aovDepth;
   const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
   if (a.sppChunks > 1) {
     size_t need = tileFloats4 * a.sppChunks * sizeof(float4);
@@ -1070,6 +1084,37 @@ int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* d) { SRT_GUARDED(ctx, sr
 int srtBuildBvh(const SrtSceneDesc* d, int32_t item, SrtBvhNode* out, int32_t capacity, int32_t* count, int32_t* stackDepth) { SRT_GUARDED(nullptr, srtBuildBvhImpl(d, item, out, capacity, count, stackDepth)); }
 int srtGetBvh(SrtContext* ctx, int32_t item, SrtBvhNode* nodes, int32_t capacity, int32_t* count) { SRT_GUARDED(ctx, srtGetBvhImpl(ctx, item, nodes, capacity, count)); }
 int srtRenderTiles(SrtContext* ctx, const SrtRenderParams* p, void* dAccumTiles, void* streamPtr) { SRT_GUARDED(ctx, srtRenderTilesImpl(ctx, p, dAccumTiles, streamPtr)); }
+
+/* include/srt_hip_test.h: the render kernel's own traversal, ray by ray */
+static int srtRenderAovImpl(SrtContext* ctx, const SrtRenderParams* pIn, int32_t depth, SrtAovRecord* hOut) {
+  if (!ctx || !pIn || !hOut || depth < 0) return 1;
+  SrtRenderParams p = *pIn;
+  p.spp = 1;
+  p.sppChunks = 1;
+  p.countStats = 1;
+  p.tileFirst = 0;
+  p.tileStride = 1;
+  if (checkParams(ctx, &p)) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  const size_t nPix = (size_t)p.imageWidth * p.imageHeight;
+  const size_t tileBytes = (size_t)srtNumTiles(p.imageWidth, p.imageHeight) * SRT_TILE_PIXELS * sizeof(float4);
+  void* dTiles = nullptr;
+  int rc = 1;
+  do {
+    if (hipMalloc(&dTiles, tileBytes) != hipSuccess || hipMalloc((void**)&ctx->dAov, nPix * sizeof(SrtAovRecord)) != hipSuccess) { fail(ctx, "aov: hipMalloc"); break; }
+    if (hipMemset(ctx->dAov, 0, nPix * sizeof(SrtAovRecord)) != hipSuccess) { fail(ctx, "aov: memset"); break; }
+    ctx->aovDepth = depth;
+    if (srtRenderTilesImpl(ctx, &p, dTiles, nullptr)) break;
+    if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "aov: render kernel failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hipMemcpy(hOut, ctx->dAov, nPix * sizeof(SrtAovRecord), hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "aov: copy out"); break; }
+    rc = 0;
+  } while (0);
+  if (dTiles) (void)hipFree(dTiles);
+  if (ctx->dAov) (void)hipFree(ctx->dAov);
+  ctx->dAov = nullptr;
+  return rc;
+}
+int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAovRecord* hOut) { SRT_GUARDED(ctx, srtRenderAovImpl(ctx, p, depth, hOut)); }
 
 /* include/srt_hip_test.h: sub-step profile of the counting variant's last launch */
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10) {

@@ -91,6 +91,8 @@ struct RenderArgs {
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // [chunk][localTile][64]
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr
+  SrtAovRecord* aov;          // counting variant only: per-pixel record of the ray at bounce aovDepth (srtRenderAov)
+  int32_t aovDepth;
 };
 
 struct TraceArgs {

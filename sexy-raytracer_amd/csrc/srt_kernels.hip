@@ -794,6 +794,28 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // next pending reference after the current subtree is done; ends the traversal when none is left.
   // Written with selects rather than nested branches: every divergent `if` costs the wave half a
   // dozen scalar exec-mask instructions, and the scalar unit is shared by the CU's four SIMDs.
+  uint32_t aovN0 = 0, aovB0 = 0, aovT0 = 0, aovS0 = 0;  // COUNT: counters at the start of the current ray
+  // srtRenderAov: what this kernel's own traversal made of the ray at bounce aovDepth of the first sample
+  auto writeAov = [&](int ref) {
+    SrtAovRecord r;
+    r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z;
+    r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
+    r.time = ray.time;
+    r.valid = 1;
+    r.prim = SRT_NO_HIT;
+    r.t = 0.0f;
+    if (ref != SRT_REF_DONE) {
+      const int pr = ~ref;
+      r.prim = (pr & 1) ? sc.sphPrimId[pr >> 1] : sc.triPrimId[pr >> 1];
+      r.t = closest;
+    }
+    r.nodeVisits = (int32_t)((uint32_t)cNodes - aovN0);
+    r.boxPasses = (int32_t)((uint32_t)cBox - aovB0);
+    r.triTests = (int32_t)((uint32_t)cTri - aovT0);
+    r.sphereTests = (int32_t)((uint32_t)cSph - aovS0);
+    r.pad[0] = r.pad[1] = 0;
+    a.aov[pixel] = r;
+  };
   auto popNext = [&](int next) {  // next = *sptr, read early by the caller: the sentinel when nothing is pending
     sptr -= SRT_BLOCK;
     if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
@@ -804,7 +826,13 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   };
   // world.hit(r, 0.001, infinity, rec): start the traversal of the world list
   auto startTraversal = [&]() {
-    if (COUNT) cRays++;
+    if (COUNT) {
+      cRays++;
+      aovN0 = (uint32_t)cNodes;
+      aovB0 = (uint32_t)cBox;
+      aovT0 = (uint32_t)cTri;
+      aovS0 = (uint32_t)cSph;
+    }
     rayA = lenSq(ray.d);  // sphere.h:56
     const bool certified = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
                            fastDivOperandOk(ray.o.z, ray.d.z);
@@ -966,6 +994,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         pSub[6] += nH;
       }
       if (atHit()) {
+        if (COUNT && a.aov && depth == a.aovDepth && s == a.sampleFirst) writeAov(hitRef);
         Record rec;
         int pr = ~hitRef;
         if (pr & 1)
@@ -1029,6 +1058,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       }
       if (atRestart()) {
         if (pend != 0) {
+          if (COUNT && a.aov && pend == 1 && depth == a.aovDepth && s == a.sampleFirst) writeAov(SRT_REF_DONE);
           V3 L = background;  // main.cpp:39-40
           if (pend == 2)
             L = mk(attStack[(3 * a.maxBounce + 0) * SRT_BLOCK], attStack[(3 * a.maxBounce + 1) * SRT_BLOCK],

@@ -23,9 +23,10 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
            "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks",
            "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays",
+           "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile"]
+TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtRenderAov"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -51,12 +52,17 @@ lib.srtRenderTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtResolveTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _vp, _vp]
 lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtTraceRays.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int32]
+lib.srtCommGetUniqueId.argtypes = [_vp]
+lib.srtCommInit.argtypes = [_vp, _vp, C.c_int32, C.c_int32]
+lib.srtGatherTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _vp]
+lib.srtRenderImageRanks.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
+lib.srtCommDestroy.argtypes = [_vp]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
-if hasattr(lib, "srtGetShadeProfile"):
-    lib.srtGetShadeProfile.argtypes = [_vp, _vp]
+lib.srtGetShadeProfile.argtypes = [_vp, _vp]
+lib.srtRenderAov.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), C.c_int32, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
 lib.srtDeviceInfo.argtypes = [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -110,6 +116,14 @@ def build_bvh_host(scene_builder, item=0, reset_rng=True):
     return nodes, sd.value
 
 
+def comm_unique_id():
+    """128 opaque bytes from RCCL (rank 0 calls this and hands them to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    if lib.srtCommGetUniqueId(buf):
+        raise SrtError("srtCommGetUniqueId failed")
+    return buf.raw
+
+
 class Context:
     """One per GPU (glDevice's role, gl.h:16-40)."""
 
@@ -143,6 +157,18 @@ class Context:
 
     def set_camera(self, cam):
         self._check(lib.srtSetCamera(self.h, C.byref(cam)))
+        self._camera_bytes = bytes(cam)
+
+    def fingerprint(self):
+        """sha1 over the uploaded scene description and the camera: what a checkpoint of accumulated samples
+        belongs to (progressive.py)."""
+        import hashlib
+        h = hashlib.sha1()
+        if self._scene_keep is not None:
+            for a in self._scene_keep[0]._keep:
+                h.update(bytes(memoryview(a)) if not hasattr(a, "tobytes") else a.tobytes())
+        h.update(getattr(self, "_camera_bytes", b""))
+        return h.hexdigest()
 
     def bvh(self, item=0):
         n = C.c_int32(0)
@@ -169,6 +195,25 @@ class Context:
 
     def resolve_tiles(self, params, d_gathered_ptr, d_rgba_ptr=None, d_accum_image_ptr=None, stream=None):
         self._check(lib.srtResolveTiles(self.h, C.byref(params), d_gathered_ptr, d_rgba_ptr, d_accum_image_ptr, stream))
+
+    def comm_init(self, unique_id, num_ranks, rank):
+        self._check(lib.srtCommInit(self.h, C.c_char_p(unique_id), num_ranks, rank))
+
+    def gather_tiles(self, params, d_local_ptr, d_gathered_ptr=None, stream=None):
+        """The path's one collective: ncclGather of the ranks' tile buffers to rank 0 (srt_comm.cpp)."""
+        self._check(lib.srtGatherTiles(self.h, C.byref(params), d_local_ptr, d_gathered_ptr, stream))
+
+    def render_image_ranks(self, params, want_accum=True, want_rgba=True):
+        """Collective blocking render across the communicator's ranks; rank 0 gets the image."""
+        W, H = params.imageWidth, params.imageHeight
+        accum = np.zeros((H, W, 4), np.float32) if want_accum else None
+        rgba = np.zeros((H, W, 4), np.uint8) if want_rgba else None
+        self._check(lib.srtRenderImageRanks(self.h, C.byref(params), accum.ctypes.data if want_accum else None,
+                                            rgba.ctypes.data if want_rgba else None))
+        return accum, rgba
+
+    def comm_destroy(self):
+        self._check(lib.srtCommDestroy(self.h))
 
     def trace(self, rays, traversal=abi.SRT_TRAVERSE_FAITHFUL):
         rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
@@ -198,6 +243,13 @@ class Context:
         v = C.c_int32(0)
         self._check(lib.srtGetTunable(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def render_aov(self, params, depth=0):
+        """The render kernel's own traversal of the ray at bounce `depth` of every pixel's first sample
+        (include/srt_hip_test.h): returns an AOV_DTYPE array (H, W)."""
+        out = np.zeros((params.imageHeight, params.imageWidth), abi.AOV_DTYPE)
+        self._check(lib.srtRenderAov(self.h, C.byref(params), depth, out.ctypes.data))
+        return out
 
     def shade_profile(self):
         out = np.zeros(10, np.uint64)

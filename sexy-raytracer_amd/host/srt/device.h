@@ -3,6 +3,9 @@
 //   init(w, h, world)                       flatten (populate) + upload to HBM
 //   rtFrame(target, w, h, cam, bg, spp, b)  render the frame into the caller-owned RGBA8 target
 //   terminate()
+//   uniqueId / initRanks                    multi-GPU: one process per GPU; rtFrame then renders this rank's
+//                                           tiles, the library gathers them with ONE ncclGather and rank 0's
+//                                           target receives the frame (include/srt_hip.h "Multi-GPU")
 // Returns bool and reports on std::cerr like the reference.  There is no CPU fallback.
 #ifndef SRT_HOST_DEVICE_H
 #define SRT_HOST_DEVICE_H
@@ -35,6 +38,16 @@ class hipDevice {
     return true;
   }
 
+  // Multi-GPU.  Rank 0 obtains an id (128 bytes) and hands it to the other processes by its own means;
+  // every process then calls initRanks after init.  Single-process programs never call these.
+  static bool uniqueId(void* id128) { return srtCommGetUniqueId(id128) == 0; }
+  bool initRanks(const void* id128, int numRanks, int rank) {
+    if (!ctx) return false;
+    if (srtCommInit(ctx, id128, numRanks, rank) != 0) return error();
+    ranks = numRanks;
+    return true;
+  }
+
   // the pixel loop main.cpp:200-227 for the whole frame; frameData = uint8[w*h*4] (main.cpp:182)
   bool rtFrame(void* frameData, int w, int h, const camera& cam, const color3f& background, int numSamples,
                int maxBounce, uint64_t seed = 1, float* accum = nullptr) {
@@ -47,7 +60,11 @@ class hipDevice {
     p.traversal = SRT_TRAVERSE_FAITHFUL;
     p.tileFirst = 0; p.tileStride = 1;
     p.sppChunks = sppChunks;
-    if (srtRenderImage(ctx, &p, accum, static_cast<uint8_t*>(frameData)) != 0) return error();
+    if (ranks > 1) {  // collective: every rank renders its tiles, one gather, rank 0 fills its target
+      if (srtRenderImageRanks(ctx, &p, accum, static_cast<uint8_t*>(frameData)) != 0) return error();
+    } else if (srtRenderImage(ctx, &p, accum, static_cast<uint8_t*>(frameData)) != 0) {
+      return error();
+    }
     (void)srtLastKernelMs(ctx, &lastKernelMs);
     return true;
   }
@@ -75,6 +92,7 @@ class hipDevice {
   }
   SrtContext* ctx = nullptr;
   int width = 0, height = 0;
+  int ranks = 1;
 };
 
 #endif

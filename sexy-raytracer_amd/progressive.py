@@ -4,7 +4,9 @@ The reference renders all samples in one go and writes the PNG once at the end (
 a 5000-spp run that dies loses everything.  Here a frame is rendered in passes of `pass_spp`
 samples (SrtRenderParams.sampleFirst selects the absolute sample range, so the passes add up to
 exactly the samples a single render would draw); after every pass the float accumulators and the
-next sample index can be written to an .npz and picked up again later."""
+next sample index can be written to an .npz and picked up again later.  A checkpoint records the
+fingerprint of the scene and camera it was rendered with; resuming on a context that holds anything else
+is refused."""
 import os
 
 import numpy as np
@@ -29,12 +31,15 @@ class ProgressiveRender:
     def save(self, path):
         tmp = path + ".tmp.npz"
         np.savez(tmp, accum=self.accum, next_sample=self.next_sample, width=self.width, height=self.height,
-                 max_bounce=self.max_bounce, seed=self.seed, background=np.asarray(self.background, np.float32))
+                 max_bounce=self.max_bounce, seed=self.seed, background=np.asarray(self.background, np.float32),
+                 fingerprint=np.array(self.ctx.fingerprint()))
         os.replace(tmp, path)
 
     @classmethod
     def resume(cls, ctx, abi, path):
         z = np.load(path)
+        if "fingerprint" in z.files and str(z["fingerprint"]) != ctx.fingerprint():
+            raise ValueError("checkpoint %s was rendered with a different scene or camera than the context holds" % path)
         self = cls(ctx, abi, int(z["width"]), int(z["height"]), int(z["max_bounce"]), int(z["seed"]),
                    tuple(float(x) for x in z["background"]))
         self.accum = z["accum"].copy()

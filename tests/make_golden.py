@@ -1,6 +1,10 @@
 """Generates the fixtures under tests/golden/.  Run in the build container (needs
 /root/reference for the published images); the GPU box only ever sees the outputs.
 
+  published_blocks.npz    the same two renders as 4x4-pixel block means (fixed point, 1/64 level) + a per-pixel
+                          class map (what a pinhole primary ray hits: sky / mesh / ground / light / iron /
+                          metal, traced by the oracle) + the coordinates of their pure-black pixels: ~40 000
+                          numbers per image for the pooled-residual parity checks instead of five.
   published_regions.json  region means of the reference's two published renders
                           (images/test-1kx240p.png, images/test-5kx720p.png): the only
                           outputs the reference ships; statistical parity anchors.
@@ -57,11 +61,50 @@ def secondary_rays(hits, primaries, seed=5):
     return sec
 
 
+def primary_classes(W, H):
+    """Per pixel: what a pinhole ray through the pixel centre hits in the main.cpp scene
+    (0 sky, 1 mesh, 2 ground, 3 light sphere, 4 iron sphere, 5 metal sphere)."""
+    sb = srt.scenes.scene_masterchief()
+    osc = O.OracleScene(sb)
+    cam = O.make_camera(abi.default_camera_params())
+    ys, xs = np.mgrid[0:H, 0:W]
+    u = ((xs + 0.5) / (W - 1)).astype(np.float32).ravel()            # main.cpp:210
+    v = (((H - ys) + 0.5) / (H - 1)).astype(np.float32).ravel()      # main.cpp:211
+    o = np.array(cam.origin[:], np.float32)
+    ll, hz, vt = (np.array(a[:], np.float32) for a in (cam.lleft, cam.horizontal, cam.vertical))
+    rays = np.zeros(W * H, abi.RAY_DTYPE)
+    rays["o"] = o
+    rays["d"] = (ll[None] + u[:, None] * hz[None] + v[:, None] * vt[None] - o[None]).astype(np.float32)
+    rays["tMin"], rays["tMax"] = 0.001, np.inf
+    prim = osc.trace(rays)["prim"]
+    ntri = int(sb.desc().numTriangles)
+    cls = np.zeros(W * H, np.uint8)
+    cls[(prim >= 0) & (prim < ntri)] = 1
+    for k, c in enumerate((2, 3, 4, 5)):  # scene_masterchief appends ground, light, iron, metal after the mesh
+        cls[prim == ntri + k] = c
+    return cls.reshape(H, W)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     from PIL import Image
     ref = "/root/reference/images"
     if os.path.isdir(ref):
+        blocks = {}
+        for key, name in (("240p", "test-1kx240p.png"), ("720p", "test-5kx720p.png")):
+            im = np.asarray(Image.open(os.path.join(ref, name)).convert("RGB")).astype(np.float64)
+            H, W = im.shape[:2]
+            hb, wb = H // 4, W // 4
+            b = im[:hb * 4, :wb * 4].reshape(hb, 4, wb, 4, 3).mean((1, 3))
+            blocks[key + "_block4_x64"] = np.round(b * 64).astype(np.uint16)
+            # the same blocks in linear radiance, ((q + 0.5) / 256)^2 per pixel (color.h:33-40 inverted at the
+            # centre of the quantisation step), for comparisons against low-spp renders pooled before tone mapping
+            lin = (((im + 0.5) / 256.0) ** 2)[:hb * 4, :wb * 4].reshape(hb, 4, wb, 4, 3).mean((1, 3))
+            blocks[key + "_block4_linear_x65535"] = np.round(lin * 65535).astype(np.uint16)
+            blocks[key + "_class"] = primary_classes(W, H)
+            ys, xs = np.nonzero(im.sum(2) == 0)
+            blocks[key + "_black_yx"] = np.stack([ys, xs], 1).astype(np.int16)
+        np.savez_compressed(os.path.join(GOLD, "published_blocks.npz"), **blocks)
         out = {}
         for name, scale in (("test-1kx240p.png", 1), ("test-5kx720p.png", 3)):
             im = np.asarray(Image.open(os.path.join(ref, name)).convert("RGB")).astype(np.float64)

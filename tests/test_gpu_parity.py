@@ -260,3 +260,35 @@ def test_scatter_known_answers(ctx, oracle, abi, scenes):
         np.testing.assert_allclose(got[:, 10:13], want[:, 10:13], rtol=0, atol=0)  # emitted
         frac = (_bits(got[:, 0:3]) == _bits(want[:, 0:3])).mean()
         assert frac > 0.97, frac
+
+
+@pytest.mark.parametrize("name,bounces", [("masterchief", 4), ("spheres", 8), ("iron", 4)])
+def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, camera, name, bounces):
+    """srtTraceRays runs its own kernel; this pins the RENDER kernel's node / primitive steps ray by ray
+    (VERDICT r1 item 4): srtRenderAov records, per pixel, the ray srt_render_kernel traced at bounce
+    `depth` of the first sample and the hit, t and counters its scheduler-driven traversal (one-FMA slab
+    certificate, LDS stack with sentinel, node bursts) produced; the oracle's world.hit() (bvh.h:97-105
+    recursion, IEEE divisions) on the same rays must agree bit for bit, counters included."""
+    sb = scenes[name]
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    W, H = 426, 240
+    p = abi.default_render_params(W, H, 1, bounces, seed=5)
+    seen = 0
+    for depth in range(3):
+        aov = ctx.render_aov(p, depth).reshape(-1)
+        rec = aov[aov["valid"] == 1]
+        if depth == 0:
+            assert len(rec) == W * H  # every pixel traces a camera ray
+        assert len(rec) > 1000
+        rays = np.zeros(len(rec), abi.RAY_DTYPE)
+        rays["o"], rays["d"], rays["time"] = rec["o"], rec["d"], rec["time"]
+        rays["tMin"], rays["tMax"] = 0.001, np.inf
+        want = osc.trace(rays)
+        assert np.array_equal(rec["prim"], want["prim"]), (name, depth)
+        m = want["prim"] >= 0
+        assert np.array_equal(_bits(rec["t"][m]), _bits(want["t"][m])), (name, depth)
+        assert_counters_equal(rec, want)
+        seen += len(rec)
+    assert seen > 2 * W * H

@@ -101,6 +101,24 @@ def test_published_image_region_means(oracle, srt, abi):
     assert (rgba[5:60, 5:150, :3] == np.array([186, 230, 245])).all()
 
 
+def test_published_image_class_biases(oracle, srt, abi):
+    """The oracle against the published 240p render block by block (tests/published.py): summed linear
+    radiance of every 4x4 block lying wholly on the mesh / the ground / the sky vs the published image's
+    linearised blocks (~2 500 ground, ~350 mesh and ~2 700 sky blocks).  64 spp: the statistical error of
+    a class total is 1-2 % (the light sphere's rare 250x samples dominate it); a wrong uv rule, v flip,
+    normal-map axis or Fresnel constant moves a class by 10 % and more.  The GPU twin at the published
+    sample counts is test_gpu_properties.py::test_headline_frame_pooled_residuals_vs_published."""
+    import published
+    sb = srt.scenes.scene_masterchief()
+    cam = oracle.make_camera(abi.default_camera_params())
+    p = abi.default_render_params(426, 240, 64, 4, seed=1)
+    acc, _, _ = oracle.OracleScene(sb).render(cam, p, oracle.RNG_COUNTER, threads=8, want_rgba=False)
+    bias = published.class_bias_linear(acc, 64, "240p")
+    assert abs(bias["sky"]) <= 0.002, bias      # the background colour itself (quantisation only)
+    assert abs(bias["ground"]) <= 0.03, bias
+    assert abs(bias["mesh"]) <= 0.05, bias
+
+
 def test_golden_renders_reproduce(oracle, srt, abi):
     """The committed tiny renders are reproduced bit for bit in both RNG modes (MT mode: a
     fresh generator feeds the BVH build and then the render, like a new process)."""

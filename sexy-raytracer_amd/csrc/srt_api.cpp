@@ -22,8 +22,8 @@
 #include "srt_device.h"
 
 extern "C" {
-int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
-int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU);
+int srt_launch_render(const RenderArgs* a, int kernel, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_render_occupancy(int kernel, int traversal, int count, size_t ldsBytes, int* blocksPerCU);
 int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
@@ -226,6 +226,7 @@ struct Tunables {
   int shadeMin, primMin, hitMin, fuseMin, nodeBurst;
   int plocRadius, fastDiv;
   int maxLiveChunks;
+  int kernel, swapMin;
 };
 
 struct SrtContext {
@@ -252,6 +253,7 @@ struct SrtContext {
   SrtAovRecord* dAov = nullptr;  // set only for the duration of srtRenderAov
   int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
+  DeviceBuffer attScratch;  // two-path kernel: attenuation stacks
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
   SrtStats lastStats{};
@@ -317,11 +319,15 @@ const TunableName kTunables[] = {
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"max_live_chunks", "SRT_MAX_LIVE_CHUNKS", &Tunables::maxLiveChunks, -1},
+    {"kernel", "SRT_KERNEL", &Tunables::kernel, 2},       // 1: one path per lane, 2: two paths per lane
+    {"swap_min", "SRT_SWAP_MIN", &Tunables::swapMin, 8},
 };
 
-size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
-  // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
-  return (size_t)(ctx->scene.stackDepth + 2 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
+size_t ldsBytesFor(const SrtContext* ctx, int maxBounce, int kernel) {
+  // per-thread stacks plus one word of queue state per wave; the two-path kernel keeps only the traversal
+  // stack in LDS (its attenuation stacks are in HBM)
+  const int slots = ctx->scene.stackDepth + 2 + (kernel == 2 ? 0 : 3 * maxBounce + 3);
+  return (size_t)slots * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 
 }  // namespace
@@ -438,6 +444,7 @@ int srtDestroy(SrtContext* ctx) {
   (void)srtCommDestroy(ctx);
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
+  if (ctx->attScratch.p) (void)hipFree(ctx->attScratch.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
   if (ctx->dStats) (void)hipFree(ctx->dStats);
   if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -893,17 +900,30 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   } else {
     a.out = static_cast<float4*>(dAccumTiles);
   }
-  const size_t lds = ldsBytesFor(ctx, p->maxBounce);
+  const int kernel = ctx->tun.kernel == 1 ? 1 : 2;
+  const size_t lds = ldsBytesFor(ctx, p->maxBounce, kernel);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   int perCU = 0;
-  if (srt_render_occupancy(p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  if (srt_render_occupancy(kernel, p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
+  a.swapMin = std::max(1, ctx->tun.swapMin);
+  if (kernel == 2) {
+    a.attThreads = grid * 256;
+    const size_t need = (size_t)2 * std::max(1, p->maxBounce) * a.attThreads * 3 * sizeof(float);
+    if (ctx->attScratch.bytes < need) {
+      if (ctx->attScratch.p) HIP_OK(ctx, hipFree(ctx->attScratch.p));
+      ctx->attScratch = DeviceBuffer();
+      HIP_OK(ctx, hipMalloc(&ctx->attScratch.p, need));
+      ctx->attScratch.bytes = need;
+    }
+    a.attBuf = static_cast<float*>(ctx->attScratch.p);
+  }
+  int rc = srt_launch_render(&a, kernel, p->traversal, p->countStats, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;

@@ -88,6 +88,9 @@ struct RenderArgs {
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
   int32_t nodeBurst;          // max node visits per scheduling decision
+  int32_t swapMin;            // two-path kernel: lanes wanting to exchange their slots before the exchange runs
+  float* attBuf;              // two-path kernel: attenuation stacks, [path id 0/1][bounce][attThreads] x 3 floats
+  int32_t attThreads;         // threads of the launch (grid x 256)
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // [chunk][localTile][64]
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr

@@ -120,6 +120,30 @@ def test_image_independent_of_work_distribution(ctx, abi, srt, camera):
             ctx.set_tunable(k, v)
 
 
+@pytest.mark.parametrize("scene,bounces", [("masterchief", 4), ("spheres", 8), ("sphere_field", 8)])
+def test_two_paths_per_lane_kernel_is_bit_identical(ctx, abi, srt, camera, scene, bounces):
+    """srt_render2_kernel (two paths in flight per lane, the default) and srt_render_kernel (one) draw the
+    same random numbers per (pixel, sample) and add samples and chunks in the same order: accumulators,
+    RGBA and every counter must be bit-identical, for the reference's single running sum and for the chunked
+    default, for whole frames and for a rank's share of the tiles."""
+    ctx.upload_scene(srt.scenes.SCENES[scene]())
+    ctx.set_camera(camera)
+    try:
+        for (w, h, spp, chunks, first, stride) in ((203, 117, 24, 1, 0, 1), (426, 240, 64, 0, 0, 1), (160, 90, 40, 5, 0, 1)):
+            p = abi.default_render_params(w, h, spp, bounces, seed=13, spp_chunks=chunks, count_stats=1)
+            out = {}
+            for kernel in (1, 2):
+                ctx.set_tunable("kernel", kernel)
+                acc, rgba = ctx.render_image(p)
+                out[kernel] = (acc, rgba, {k: v for k, v in ctx.stats().items() if not k.startswith(("cycles", "steps", "lanes"))})
+            assert np.array_equal(np.ascontiguousarray(out[1][0]).view(np.uint32), np.ascontiguousarray(out[2][0]).view(np.uint32)), (w, h, spp, chunks)
+            assert np.array_equal(out[1][1], out[2][1])
+            assert out[1][2] == out[2][2], (out[1][2], out[2][2])
+            assert (out[2][0][..., 3] == spp).all()
+    finally:
+        ctx.set_tunable("kernel", 2)
+
+
 def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
     sb = srt.scenes.scene_spheres()
     ctx.upload_scene(sb)

@@ -194,11 +194,14 @@ typedef struct SrtRenderParams {
   int32_t traversal;   /* SRT_TRAVERSE_* */
   /* multi-GPU tile split: this call renders tiles tileFirst, tileFirst+tileStride, ... */
   int32_t tileFirst, tileStride;
-  /* One work item = one pixel x one chunk of its samples.  Samples are summed in index order
-   * inside a chunk and the chunk sums in chunk order.  1 = a single running sum per pixel, the
-   * reference's order (main.cpp:204-218), bit-reproducible against the oracle; 0 = library
-   * default srtDefaultSppChunks(spp) (fastest; differs from 1 only by the re-association of the
-   * per-pixel float sum). */
+  /* One work item = one pixel x one chunk of its samples.  Samples are summed in index order inside a
+   * chunk (a float running sum, main.cpp:217).  1 = a single running sum per pixel, the reference's order
+   * (main.cpp:204-218), bit-reproducible against the oracle.  > 1: the chunks' float sums are added EXACTLY
+   * (64-bit fixed point with 2^-32 resolution, integer atomics) and rounded to float once, so the pixel sum
+   * does not depend on the order in which chunks finish, on the tile split or on the GPU count, and needs
+   * 32 bytes of scratch per pixel whatever the chunk count; it differs from the single running sum only by
+   * the re-association of the float sum (<= 2e-5 relative).  0 = library default
+   * srtDefaultSppChunks(spp) (fastest). */
   int32_t sppChunks;
   int32_t countStats; /* 1: run the counting variant and fill srtGetStats() */
   /* progressive rendering: this call renders samples [sampleFirst, sampleFirst + spp) of every

@@ -22,9 +22,9 @@
 #include "srt_device.h"
 
 extern "C" {
-int srt_launch_render(const RenderArgs* a, int kernel, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
-int srt_render_occupancy(int kernel, int traversal, int count, size_t ldsBytes, int* blocksPerCU);
-int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream);
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU);
+int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
@@ -226,7 +226,6 @@ struct Tunables {
   int shadeMin, primMin, hitMin, fuseMin, nodeBurst;
   int plocRadius, fastDiv;
   int maxLiveChunks;
-  int kernel, swapMin;
 };
 
 struct SrtContext {
@@ -253,7 +252,6 @@ struct SrtContext {
   SrtAovRecord* dAov = nullptr;  // set only for the duration of srtRenderAov
   int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
-  DeviceBuffer attScratch;  // two-path kernel: attenuation stacks
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
   SrtStats lastStats{};
@@ -319,15 +317,11 @@ const TunableName kTunables[] = {
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"max_live_chunks", "SRT_MAX_LIVE_CHUNKS", &Tunables::maxLiveChunks, -1},
-    {"kernel", "SRT_KERNEL", &Tunables::kernel, 2},       // 1: one path per lane, 2: two paths per lane
-    {"swap_min", "SRT_SWAP_MIN", &Tunables::swapMin, 8},
 };
 
-size_t ldsBytesFor(const SrtContext* ctx, int maxBounce, int kernel) {
-  // per-thread stacks plus one word of queue state per wave; the two-path kernel keeps only the traversal
-  // stack in LDS (its attenuation stacks are in HBM)
-  const int slots = ctx->scene.stackDepth + 2 + (kernel == 2 ? 0 : 3 * maxBounce + 3);
-  return (size_t)slots * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
+size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
+  // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
+  return (size_t)(ctx->scene.stackDepth + 2 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 
 }  // namespace
@@ -444,7 +438,6 @@ int srtDestroy(SrtContext* ctx) {
   (void)srtCommDestroy(ctx);
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
-  if (ctx->attScratch.p) (void)hipFree(ctx->attScratch.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
   if (ctx->dStats) (void)hipFree(ctx->dStats);
   if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -836,6 +829,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.imageWidth = p->imageWidth;
   a.imageHeight = p->imageHeight;
   a.tilesX = (p->imageWidth + SRT_TILE_W - 1) / SRT_TILE_W;
+  a.tilesY = (p->imageHeight + SRT_TILE_H - 1) / SRT_TILE_H;
   a.tileBlock = std::max(1, ctx->tun.tileBlock);
   a.numTiles = srtNumTiles(p->imageWidth, p->imageHeight);
   a.spp = p->spp;
@@ -877,6 +871,19 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     }
   }
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
+  a.sppBase = a.spp / a.sppChunks;
+  a.sppRem = a.spp % a.sppChunks;
+  {
+    // the launch's invariant divisors (srtDiv, srtTileFromOrderFast)
+    const int B = a.tileBlock, hLast = a.tilesY % B, wLast = a.tilesX % B;
+    a.divUnitItems = srtMakeDivisor((uint32_t)a.unitTiles * a.sppChunks * SRT_TILE_PIXELS);
+    a.divChunks = srtMakeDivisor((uint32_t)a.sppChunks);
+    a.divRow = srtMakeDivisor((uint32_t)B * a.tilesX);
+    a.divBlockFull = srtMakeDivisor((uint32_t)B * B);
+    a.divBlockLast = srtMakeDivisor((uint32_t)B * (hLast ? hLast : B));
+    a.divB = srtMakeDivisor((uint32_t)B);
+    a.divWLast = srtMakeDivisor((uint32_t)(wLast ? wLast : B));
+  }
   a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
   a.shadeMin = ctx->tun.shadeMin;
   a.primMin = ctx->tun.primMin;
@@ -887,50 +894,38 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.stats = p->countStats ? ctx->dStats : nullptr;
   a.aov = p->countStats ? ctx->dAov : nullptr;
   a.aovDepth = ctx->aovDepth;
-  const size_t tileFloats4 = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
+  const size_t tilePixels = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
+  a.out = static_cast<float4*>(dAccumTiles);
+  a.fix = nullptr;
   if (a.sppChunks > 1) {
-    size_t need = tileFloats4 * a.sppChunks * sizeof(float4);
+    // items of a pixel add their partial sums exactly (64-bit fixed point): 32 B per pixel whatever the chunk count
+    const size_t need = tilePixels * sizeof(SrtFixedAccum);
     if (ctx->chunkScratch.bytes < need) {
       if (ctx->chunkScratch.p) HIP_OK(ctx, hipFree(ctx->chunkScratch.p));
       ctx->chunkScratch = DeviceBuffer();
       HIP_OK(ctx, hipMalloc(&ctx->chunkScratch.p, need));
       ctx->chunkScratch.bytes = need;
     }
-    a.out = static_cast<float4*>(ctx->chunkScratch.p);
-  } else {
-    a.out = static_cast<float4*>(dAccumTiles);
+    a.fix = static_cast<SrtFixedAccum*>(ctx->chunkScratch.p);
+    HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
   }
-  const int kernel = ctx->tun.kernel == 1 ? 1 : 2;
-  const size_t lds = ldsBytesFor(ctx, p->maxBounce, kernel);
+  const size_t lds = ldsBytesFor(ctx, p->maxBounce);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   int perCU = 0;
-  if (srt_render_occupancy(kernel, p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  if (srt_render_occupancy(p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
   if (grid < 1) grid = 1;
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  a.swapMin = std::max(1, ctx->tun.swapMin);
-  if (kernel == 2) {
-    a.attThreads = grid * 256;
-    const size_t need = (size_t)2 * std::max(1, p->maxBounce) * a.attThreads * 3 * sizeof(float);
-    if (ctx->attScratch.bytes < need) {
-      if (ctx->attScratch.p) HIP_OK(ctx, hipFree(ctx->attScratch.p));
-      ctx->attScratch = DeviceBuffer();
-      HIP_OK(ctx, hipMalloc(&ctx->attScratch.p, need));
-      ctx->attScratch.bytes = need;
-    }
-    a.attBuf = static_cast<float*>(ctx->attScratch.p);
-  }
-  int rc = srt_launch_render(&a, kernel, p->traversal, p->countStats, grid, lds, stream);
+  int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;
-  if (a.sppChunks > 1) {
-    rc = srt_launch_combine(a.out, (int)tileFloats4, a.sppChunks, stream);
-    if (rc) return fail(ctx, "combine launch failed: %s", hipGetErrorString((hipError_t)rc));
-    HIP_OK(ctx, hipMemcpyAsync(dAccumTiles, a.out, tileFloats4 * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+  if (a.fix) {
+    rc = srt_launch_finalize(a.fix, static_cast<float4*>(dAccumTiles), (int)tilePixels, stream);
+    if (rc) return fail(ctx, "finalize launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
   return 0;
 }

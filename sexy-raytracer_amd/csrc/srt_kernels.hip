@@ -702,6 +702,32 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
   r.time = rng.uniform(c.time0, c.time1);
 }
 
+// Chunk sums of a pixel (sppChunks > 1) are added EXACTLY: every item converts its float partial sum to
+// 64-bit fixed point (2^-32) and adds it with one integer atomic per channel.  Integer addition is
+// associative, so the pixel sum does not depend on which chunk finishes first (items of a pixel run on
+// different waves and end in any order), needs no per-chunk scratch (32 B per pixel instead of
+// chunks x 16 B) and no ordered reduction pass; srt_finalize_kernel rounds the exact sum to float once.
+// Partial sums of 2^-8 and more convert exactly (their float ulp is >= 2^-32); smaller ones are rounded
+// to 2^-32 absolute.  NaN / infinite partial sums (the r = 0 ground BRDF produces NaN samples)
+// set per-channel flags and poison the channel as they would a float sum.  Range: |pixel sum| < 2^31.
+__device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc, int samples) {
+  const float c[3] = {acc.x, acc.y, acc.z};
+  long long* const ch = &f->r;
+  uint32_t flags = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float v = c[k];
+    if (!(fabsf(v) < 0x1p30f)) {  // NaN, infinite or beyond the fixed-point range (treated as infinite)
+      flags |= (v != v) ? (1u << k) : (v > 0.0f ? (8u << k) : (64u << k));
+    } else {
+      const long long q = __float2ll_rn(v * 0x1p32f);
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), (unsigned long long)q);
+    }
+  }
+  atomicAdd(&f->count, samples);
+  if (flags) atomicOr(&f->flags, flags);
+}
+
 }  // namespace
 
 // =================================================================== render
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       aovS0 = (uint32_t)cSph;
     }
     rayA = lenSq(ray.d);  // sphere.h:56
-    const bool certified = sc.fastDivScene != 0 && fastDivOperandOk(ray.o.x, ray.d.x) && fastDivOperandOk(ray.o.y, ray.d.y) &&
+    const bool certified = (sc.fastDivScene != 0) & fastDivOperandOk(ray.o.x, ray.d.x) & fastDivOperandOk(ray.o.y, ray.d.y) &
                            fastDivOperandOk(ray.o.z, ray.d.z);
     rcpD = mk(refinedRcp(ray.d.x), refinedRcp(ray.d.y), refinedRcp(ray.d.z));
     slabSetup(ray.o, rcpD, certified, negOR, slabTol);
@@ -1076,7 +1102,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         }
         if (s >= sEnd) {
           // work item finished (or none yet): write it, pull the next one with one atomic per wave
-          if (outIndex >= 0) a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
+          if (outIndex >= 0) {
+            if (a.fix)
+              commitFixed(a.fix + outIndex, acc, sCount);
+            else
+              a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
+          }
           const unsigned long long mF = __ballot(1);
           const int leader = __ffsll((long long)mF) - 1;
           int base = 0;
@@ -1121,19 +1152,20 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             s = sEnd = 0;
           } else {
             // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk
-            const int u = idx / unitItems, inUnit = idx - u * unitItems;
+            const int u = srtDiv(idx, a.divUnitItems), inUnit = idx - u * unitItems;
             const int group = inUnit >> 6, ln = inUnit & 63;
-            const int tileInUnit = group / a.sppChunks, chunk = group - tileInUnit * a.sppChunks;
+            const int tileInUnit = srtDiv(group, a.divChunks), chunk = group - tileInUnit * a.sppChunks;
             const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
             const int tile = a.tileFirst + localTile * a.tileStride;
             int tx, ty;
-            srtTileFromOrder(tile < a.numTiles ? tile : 0, a.tilesX, a.numTiles / a.tilesX, a.tileBlock, tx, ty);
+            srtTileFromOrderFast(tile < a.numTiles ? tile : 0, a.tilesX, a.tilesY, a.tileBlock, a.divRow, a.divBlockFull,
+                                 a.divBlockLast, a.divB, a.divWLast, tx, ty);
             px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
             py = ty * SRT_TILE_H + (ln >> 3);
             pixel = (uint32_t)(py * a.imageWidth + px);
-            // spp split: chunk c gets samples [c*spp/K, (c+1)*spp/K)
-            const int s0 = a.sampleFirst + (int)(((long long)a.spp * chunk) / a.sppChunks);
-            const int s1 = a.sampleFirst + (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
+            // spp split: the first sppRem chunks get sppBase + 1 samples, the others sppBase
+            const int s0 = a.sampleFirst + chunk * a.sppBase + min(chunk, a.sppRem);
+            const int s1 = s0 + a.sppBase + (chunk < a.sppRem ? 1 : 0);
             sCount = s1 - s0;
             // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
             const bool valid = localTile < a.numLocalTiles && tile < a.numTiles && px < a.imageWidth && py < a.imageHeight &&
@@ -1141,7 +1173,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             s = s0;
             sEnd = valid ? s1 : s0;
             acc = mk(0.0f, 0.0f, 0.0f);
-            outIndex = localTile < a.numLocalTiles ? (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln : -1;
+            outIndex = localTile < a.numLocalTiles ? localTile * SRT_TILE_PIXELS + ln : -1;
           }
         }
         if (alive && s < sEnd) {
@@ -1179,467 +1211,23 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   }
 }
 
-// =================================================================== render, two paths per lane
-// The same loop (main.cpp:200-227) with TWO work items in flight per lane, of which at most one is being
-// traversed at any time:
-//   T  the traversing slot: its ray walks the BVH in the node / primitive steps (LDS stack, as above);
-//   P  the parked slot: a path whose traversal is finished and which waits for a hit-shading or restart step,
-//      or which already holds its next ray (READY) and waits for T to finish.
-// A lane whose T has finished exchanges T and P (20 registers) as soon as P is READY and goes on traversing,
-// so lanes keep walking the tree while their other path waits for a well-filled shading step, and the
-// shading / restart steps draw on a pool of 64 parked paths that does not stall the traversal.  A finished
-// path has an empty traversal stack, so one LDS stack per lane serves both slots; the per-bounce
-// attenuations of the two paths live in HBM ([slot][bounce][thread] x 12 B, one dwordx3 store per bounce,
-// read back at path end) instead of LDS, which leaves LDS = the traversal stack alone.
-// Per (pixel, sample) RNG keys, sample order inside an item and the item sums are those of
-// srt_render_kernel: the image is bit-identical (tests/test_gpu_properties.py).
-#ifndef SRT_RENDER2_WAVES_PER_SIMD
-#define SRT_RENDER2_WAVES_PER_SIMD 4
-#endif
-struct PathSlot {
-  Ray ray;        // the path's current ray; after a path end, ray.d holds its terminal radiance
-  float closest;  // traversal result
-  int hitRef;
-  Pcg rng;
-  int depth, pend;  // pend: 0 nothing to add, 1 miss (background), 2 terminal radiance in ray.d
-  int st;           // 0 dead / empty, 1 waits for a restart step, 2 waits for a hit-shading step, 3 has a ray (T: traversing)
-  int id;           // which half of the attenuation buffer this path owns (travels with the slot)
-  int s, sEnd, sCount, outIndex, pxy;
-  V3 acc;
-  uint32_t cnt[4];  // COUNT: node visits, box passes, triangle tests, sphere tests of the finished ray
-};
-struct Att3 {
-  float x, y, z;
-};
-// exchange of the two slots of a lane, one v_swap_b32 per register (the compiler's three moves per register
-// cost three times the issue slots)
-__device__ __forceinline__ void swapReg(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swapReg(int& a, int& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swapReg(uint32_t& a, uint32_t& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-template <bool COUNT>
-__device__ __forceinline__ void swapSlots(PathSlot& x, PathSlot& y) {
-  swapReg(x.ray.o.x, y.ray.o.x); swapReg(x.ray.o.y, y.ray.o.y); swapReg(x.ray.o.z, y.ray.o.z);
-  swapReg(x.ray.d.x, y.ray.d.x); swapReg(x.ray.d.y, y.ray.d.y); swapReg(x.ray.d.z, y.ray.d.z);
-  swapReg(x.ray.time, y.ray.time);
-  swapReg(x.closest, y.closest);
-  swapReg(x.hitRef, y.hitRef);
-  uint32_t xl = (uint32_t)x.rng.state, xh = (uint32_t)(x.rng.state >> 32), yl = (uint32_t)y.rng.state, yh = (uint32_t)(y.rng.state >> 32);
-  swapReg(xl, yl);
-  swapReg(xh, yh);
-  x.rng.state = ((uint64_t)xh << 32) | xl;
-  y.rng.state = ((uint64_t)yh << 32) | yl;
-  swapReg(x.depth, y.depth); swapReg(x.pend, y.pend); swapReg(x.st, y.st); swapReg(x.id, y.id);
-  swapReg(x.s, y.s); swapReg(x.sEnd, y.sEnd); swapReg(x.sCount, y.sCount); swapReg(x.outIndex, y.outIndex); swapReg(x.pxy, y.pxy);
-  swapReg(x.acc.x, y.acc.x); swapReg(x.acc.y, y.acc.y); swapReg(x.acc.z, y.acc.z);
-  if (COUNT)
-    for (int k = 0; k < 4; ++k) swapReg(x.cnt[k], y.cnt[k]);
-}
-
-template <bool CLOSEST, bool COUNT, bool SINGLE>
-__global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER2_WAVES_PER_SIMD) void srt_render2_kernel(const RenderArgs a) {
-  extern __shared__ int32_t lds[];
-  int32_t* const stackBase = lds + threadIdx.x;
-  *stackBase = SRT_REF_DONE;  // slot 0: the sentinel (see srt_render_kernel)
-  const int lane = threadIdx.x & 63;
-  const uint64_t seedMixed = mix64(a.seed);
-  const V3 background = ld3(a.background);
-  const DevScene& sc = a.scene;
-  const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
-  const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
-  const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
-  const __amdgpu_buffer_rsrc_t rsTexels = makeRsrc(sc.texels, sc.texelBytes);
-  const bool singleRoot = SINGLE || sc.numWorld == 1;
-  // attenuation stacks: entry (path id, bounce) of this thread
-  Att3* const attMine = reinterpret_cast<Att3*>(a.attBuf) + (size_t)blockIdx.x * SRT_BLOCK + threadIdx.x;
-  auto attAt = [&](int id, int bounce) -> Att3* { return attMine + (size_t)(id * a.maxBounce + bounce) * a.attThreads; };
-
-  unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
-  unsigned long long pCyc[3] = {0, 0, 0}, pSteps[3] = {0, 0, 0}, pLanes[3] = {0, 0, 0};
-  const unsigned long long pStart = COUNT ? clock64() : 0;
-
-  int32_t* waveQueue = lds + (a.scene.stackDepth + 2) * SRT_BLOCK + (threadIdx.x >> 6);
-  const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
-  if (lane == 0) *waveQueue = qHome;
-  const int unitItems = a.unitTiles * a.sppChunks * SRT_TILE_PIXELS;
-  auto queueEnd = [&](int q) { return (q < a.numUnits ? (a.numUnits - q + a.numQueues - 1) / a.numQueues : 0) * unitItems; };
-
-  PathSlot T, P;
-  auto initSlot = [&](PathSlot& x, int id) {
-    x.ray.o = x.ray.d = mk(0.0f, 0.0f, 0.0f);
-    x.ray.time = 0.0f;
-    x.closest = SRT_INF;
-    x.hitRef = SRT_REF_DONE;
-    x.rng.state = 0;
-    x.depth = x.pend = 0;
-    x.st = 1;  // waits for a restart step, which finds s >= sEnd and pulls a work item
-    x.id = id;
-    x.s = x.sEnd = x.sCount = 0;
-    x.outIndex = -1;
-    x.pxy = 0;
-    x.acc = mk(0.0f, 0.0f, 0.0f);
-    x.cnt[0] = x.cnt[1] = x.cnt[2] = x.cnt[3] = 0;
-  };
-  initSlot(T, 0);
-  initSlot(P, 1);
-
-  // traversal state of T (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
-  int cur = SRT_REF_DONE, w = 0;
-  int32_t* sptr = stackBase;
-  float rayA = 0.0f;
-  V3 rcpD = mk(0.0f, 0.0f, 0.0f), negOR = mk(0.0f, 0.0f, 0.0f);
-  float slabTol = SRT_INF;
-  int dirNeg = 0;
-  uint32_t rayN0 = 0, rayB0 = 0, rayT0 = 0, rayS0 = 0;
-  auto atNode = [&]() { return cur >= 0; };
-  auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)SRT_REF_DONE; };
-
-  auto popNext = [&](int next) {
-    sptr -= SRT_BLOCK;
-    if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {
-      next = sc.world[w];
-      sptr = stackBase;
-    }
-    cur = next;
-  };
-  // world.hit(T.ray, 0.001, infinity, rec): start the traversal of the world list
-  auto startTraversal = [&]() {
-    if (COUNT) {
-      cRays++;
-      rayN0 = (uint32_t)cNodes;
-      rayB0 = (uint32_t)cBox;
-      rayT0 = (uint32_t)cTri;
-      rayS0 = (uint32_t)cSph;
-    }
-    rayA = lenSq(T.ray.d);
-    const bool certified = (sc.fastDivScene != 0) & fastDivOperandOk(T.ray.o.x, T.ray.d.x) & fastDivOperandOk(T.ray.o.y, T.ray.d.y) &
-                           fastDivOperandOk(T.ray.o.z, T.ray.d.z);
-    rcpD = mk(refinedRcp(T.ray.d.x), refinedRcp(T.ray.d.y), refinedRcp(T.ray.d.z));
-    slabSetup(T.ray.o, rcpD, certified, negOR, slabTol);
-    if (CLOSEST) dirNeg = (T.ray.d.x < 0.0f ? 1 : 0) | (T.ray.d.y < 0.0f ? 2 : 0) | (T.ray.d.z < 0.0f ? 4 : 0);
-    T.closest = SRT_INF;
-    T.hitRef = SRT_REF_DONE;
-    sptr = stackBase;
-    w = 0;
-    cur = sc.world[0];
-  };
-  auto writeAov = [&](const PathSlot& x, uint32_t pixel) {
-    SrtAovRecord r;
-    r.o[0] = x.ray.o.x; r.o[1] = x.ray.o.y; r.o[2] = x.ray.o.z;
-    r.d[0] = x.ray.d.x; r.d[1] = x.ray.d.y; r.d[2] = x.ray.d.z;
-    r.time = x.ray.time;
-    r.valid = 1;
-    r.prim = SRT_NO_HIT;
-    r.t = 0.0f;
-    if (x.hitRef != SRT_REF_DONE) {
-      const int pr = ~x.hitRef;
-      r.prim = (pr & 1) ? sc.sphPrimId[pr >> 1] : sc.triPrimId[pr >> 1];
-      r.t = x.closest;
-    }
-    r.nodeVisits = (int32_t)x.cnt[0];
-    r.boxPasses = (int32_t)x.cnt[1];
-    r.triTests = (int32_t)x.cnt[2];
-    r.sphereTests = (int32_t)x.cnt[3];
-    r.pad[0] = r.pad[1] = 0;
-    a.aov[pixel] = r;
-  };
-
-  for (;;) {
-    // ---- T finished its traversal: it becomes a path that waits for a shading (hit) or restart (miss) step
-    if (T.st == 3 && cur == SRT_REF_DONE) {
-      const bool hit = T.hitRef != SRT_REF_DONE;
-      T.st = hit ? 2 : 1;
-      T.pend = hit ? 0 : 1;
-      if (COUNT) {
-        T.cnt[0] = (uint32_t)cNodes - rayN0;
-        T.cnt[1] = (uint32_t)cBox - rayB0;
-        T.cnt[2] = (uint32_t)cTri - rayT0;
-        T.cnt[3] = (uint32_t)cSph - rayS0;
-      }
-    }
-    // ---- exchange: a lane that is not traversing takes P's ready ray (its finished path goes to P); a finished
-    // path also moves to a dead P so that it gets shaded
-    const bool wantSwap = T.st != 3 && (P.st == 3 || (T.st != 0 && P.st == 0));
-    const unsigned long long mW = __ballot(wantSwap);
-    const unsigned long long mN = __ballot(atNode()), mP = __ballot(atPrim()), mS = __ballot(P.st == 1), mH = __ballot(P.st == 2);
-    const int nW = __popcll(mW), nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nH = __popcll(mH);
-    if ((nW | nN | nP | nS | nH) == 0) break;  // every slot of every lane is dead
-    if (nW >= a.swapMin || (nN | nP) == 0) {
-      if (wantSwap) {
-        swapSlots<COUNT>(T, P);
-        if (T.st == 3)
-          startTraversal();
-        else
-          cur = SRT_REF_DONE;
-      }
-      if (nW) continue;  // states changed: count again
-    }
-    int pick;
-    if (nH >= a.hitMin || (nN | nP | nS) == 0)
-      pick = M_HIT;
-    else if (nS >= a.shadeMin || (nN | nP) == 0)
-      pick = M_SHADE;
-    else if (nP >= a.primMin || nN == 0)
-      pick = M_PRIM;
-    else
-      pick = M_NODE;
-    if (nH == 0 && pick == M_HIT) pick = nS ? M_SHADE : (nP ? M_PRIM : M_NODE);
-    pick = __builtin_amdgcn_readfirstlane(pick);
-    unsigned long long pT0 = COUNT ? clock64() : 0;
-    int pk = pick == M_HIT ? 2 : pick;
-    if (COUNT && pick != M_NODE) {
-      pSteps[pk]++;
-      pLanes[pk] += pick == M_PRIM ? nP : (pick == M_HIT ? nH : nS);
-    }
-
-    int nNodes = nN;
-    if (pick == M_PRIM) {
-      // ------------------------------------------------ sphere::hit / triangle::hit
-      if (atPrim()) {
-        const int pending = *sptr;
-        int pr = ~cur;
-        float t;
-        bool ok;
-        if (pr & 1) {
-          if (COUNT) cSph++;
-          const int off = (pr >> 1) * 48;
-          float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
-          V3 center = mk(s0.x, s0.y, s0.z);
-          if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
-            float4 s2 = bufLoad4(rsSpheres, off + 32);
-            center = center + ((T.ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
-          }
-          ok = sphereHitV(center, s0.w, T.ray, rayA, a.tMin, T.closest, t);
-        } else {
-          if (COUNT) cTri++;
-          const int off = (pr >> 1) * 48;
-          ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), T.ray, a.tMin,
-                                T.closest, t);
-        }
-        if (ok) {
-          T.closest = t;
-          T.hitRef = cur;
-        }
-        popNext(pending);
-      }
-      nNodes = __popcll(__ballot(atNode()));
-      if (nNodes >= a.fuseMin) {
-        if (COUNT) {
-          const unsigned long long now = clock64();
-          pCyc[pk] += now - pT0;
-          pT0 = now;
-          pk = M_NODE;
-        }
-        pick = M_NODE;
-      }
-    }
-
-    if (pick == M_NODE) {
-      // ------------------------------------------------ bvhNode::hit, bvh.h:97-105 (as in srt_render_kernel)
-      const int keep = nNodes - (nNodes >> 2);
-      int budget = a.nodeBurst;
-      constexpr int UNROLL = CLOSEST ? SRT_NODE_UNROLL_CLOSEST : SRT_NODE_UNROLL;
-      auto nodeVisit = [&]() {
-        if (COUNT) {
-          pSteps[M_NODE]++;
-          pLanes[M_NODE] += __popcll(__ballot(atNode()));
-        }
-        if (atNode()) {
-          float4 n0 = bufLoad4(rsNodes, cur), n1 = bufLoad4(rsNodes, cur + 16);
-          const int axis = CLOSEST ? sc.nodeAxis[cur >> 5] : 3;
-          const int top = *sptr;
-          if (COUNT) cNodes++;
-          bool undecided;
-          bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, T.closest, undecided);
-          if (undecided) hitBox = boxHit(n0, n1, T.ray, a.tMin, T.closest);
-          if (COUNT && hitBox) cBox++;
-          int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-          if (CLOSEST) {
-            if ((dirNeg >> axis) & 1) {
-              const int tmp = left;
-              left = right;
-              right = tmp;
-            }
-          }
-          sptr[SRT_BLOCK] = right;
-          int move = hitBox ? (right != left ? 1 : 0) : -1;
-          asm("" : "+v"(move));
-          sptr += move * SRT_BLOCK;
-          cur = hitBox ? left : top;
-          if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {
-            cur = sc.world[w];
-            sptr = stackBase;
-          }
-        }
-      };
-      do {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) nodeVisit();
-        budget -= UNROLL;
-      } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
-    } else if (pick == M_HIT) {
-      // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51) on the parked path
-      if (P.st == 2) {
-        const uint32_t pixel = (uint32_t)((P.pxy >> 16) * a.imageWidth + (P.pxy & 0xffff));
-        if (COUNT && a.aov && P.depth == a.aovDepth && P.s == a.sampleFirst) writeAov(P, pixel);
-        Record rec;
-        int pr = ~P.hitRef;
-        if (pr & 1)
-          sphereRecord(sc, pr >> 1, P.ray, P.closest, rec, false);
-        else
-          triRecord(sc, pr >> 1, P.ray, P.closest, rec, false);
-        V3 att, emitted;
-        Ray next;
-        uint32_t fetches = 0;
-        if (COUNT && rec.isTri) cShTri++;
-        bool scattered = shade<COUNT>(sc, rsTexels, P.ray, rec, P.rng, att, next, emitted, fetches);
-        if (COUNT) cTex += fetches;
-        if (scattered) {
-          // emitted is (0,0,0) for every scattering material (material.h:18-20)
-          Att3 v{att.x, att.y, att.z};
-          *attAt(P.id, P.depth) = v;
-          P.ray = next;
-          P.depth++;
-          if (P.depth >= a.maxBounce) {  // main.cpp:36-37: out of bounces -> black
-            P.ray.d = mk(0.0f, 0.0f, 0.0f);
-            P.pend = 2;
-            P.st = 1;
-          } else {
-            P.st = 3;  // ready to be traversed
-          }
-        } else {
-          P.ray.d = emitted;  // the path ends here: its terminal radiance, for the restart step (main.cpp:46-47)
-          P.pend = 2;
-          P.st = 1;
-        }
-      }
-    } else if (pick == M_SHADE) {
-      // ------------------------------------------------ path restart on the parked path: miss / path end
-      // (main.cpp:39-40,49-51), pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
-      if (P.st == 1) {
-        const int ppx = P.pxy & 0xffff, ppy = P.pxy >> 16;
-        if (P.pend != 0) {
-          if (COUNT && a.aov && P.pend == 1 && P.depth == a.aovDepth && P.s == a.sampleFirst)
-            writeAov(P, (uint32_t)(ppy * a.imageWidth + ppx));
-          V3 L = P.pend == 2 ? P.ray.d : background;  // main.cpp:39-40
-          P.pend = 0;
-          // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
-          for (int j = P.depth - 1; j >= 0; --j) {
-            const Att3 v = *attAt(P.id, j);
-            L = mk(0.0f + L.x * v.x, 0.0f + L.y * v.y, 0.0f + L.z * v.z);
-          }
-          P.acc = P.acc + L;  // main.cpp:217
-          P.s++;
-        }
-        bool haveSample = P.s < P.sEnd;
-        if (!haveSample) {
-          // work item finished (or none yet): write it, pull the next one with one atomic per wave
-          if (P.outIndex >= 0) a.out[P.outIndex] = make_float4(P.acc.x, P.acc.y, P.acc.z, (float)P.sCount);
-          const unsigned long long mF = __ballot(1);
-          const int leader = __ffsll((long long)mF) - 1;
-          int base = 0;
-          const int q = *waveQueue;  // wave-uniform
-          bool gotItem = false, dead = false;
-          int idx = 0;
-          if (q >= 0) {
-            if (lane == leader) base = atomicAdd(a.queue + 16 * q, __popcll(mF));
-            base = __shfl(base, leader);
-            idx = base + __popcll(mF & ((1ull << lane) - 1ull));
-            const int qEnd = queueEnd(q);
-            gotItem = idx < qEnd;
-            if (base + __popcll(mF) > qEnd) {
-              int nq = -1;
-              if (lane == leader) {
-                int bestLeft = 0;
-                bool bestOwn = false;
-                for (int k = 0; k < a.numQueues; ++k) {
-                  const int left = queueEnd(k) - __hip_atomic_load(a.queue + 16 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  const bool own = ((k ^ qHome) & 7) == 0;
-                  if (left > 0 && ((own && !bestOwn) || (own == bestOwn && left > bestLeft))) {
-                    bestLeft = left;
-                    bestOwn = own;
-                    nq = k;
-                  }
-                }
-                *waveQueue = nq;
-              }
-              nq = __shfl(nq, leader);
-              if (!gotItem && nq < 0) dead = true;
-            }
-          } else {
-            dead = true;
-          }
-          P.outIndex = -1;
-          P.s = P.sEnd = 0;
-          if (dead) P.st = 0;
-          if (gotItem) {
-            const int u = idx / unitItems, inUnit = idx - u * unitItems;
-            const int group = inUnit >> 6, ln = inUnit & 63;
-            const int tileInUnit = group / a.sppChunks, chunk = group - tileInUnit * a.sppChunks;
-            const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
-            const int tile = a.tileFirst + localTile * a.tileStride;
-            int tx, ty;
-            srtTileFromOrder(tile < a.numTiles ? tile : 0, a.tilesX, a.numTiles / a.tilesX, a.tileBlock, tx, ty);
-            const int px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1)), py = ty * SRT_TILE_H + (ln >> 3);
-            P.pxy = px | (py << 16);
-            const int s0 = a.sampleFirst + (int)(((long long)a.spp * chunk) / a.sppChunks);
-            const int s1 = a.sampleFirst + (int)(((long long)a.spp * (chunk + 1)) / a.sppChunks);
-            P.sCount = s1 - s0;
-            const bool valid = localTile < a.numLocalTiles && tile < a.numTiles && px < a.imageWidth && py < a.imageHeight &&
-                               a.maxBounce > 0;
-            P.s = s0;
-            P.sEnd = valid ? s1 : s0;
-            P.acc = mk(0.0f, 0.0f, 0.0f);
-            P.outIndex = localTile < a.numLocalTiles ? (chunk * a.numLocalTiles + localTile) * SRT_TILE_PIXELS + ln : -1;
-            haveSample = P.s < P.sEnd;
-          }
-        }
-        if (P.st != 0 && haveSample) {
-          const int px = P.pxy & 0xffff, py = P.pxy >> 16;
-          P.rng.key(seedMixed, (uint32_t)(py * a.imageWidth + px), (uint32_t)P.s);
-          float u = ((float)px + P.rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
-          float v = ((float)(a.imageHeight - py) + P.rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
-          cameraRay(a.cam, u, v, P.rng, P.ray);
-          P.depth = 0;
-          if (COUNT) cSamples++;
-          P.st = 3;
-        }
-        // else: dead, or an empty item (pixel outside the image): stays at 1 and pulls again
-      }
-    }
-    if (COUNT) pCyc[pk] += clock64() - pT0;
-  }
-
-  if (COUNT && a.stats) {
-    unsigned long long v[8] = {cSamples, cRays, cNodes, cBox, cTri, cSph, cShTri, cTex};
-    for (int k = 0; k < 8; ++k) {
-      unsigned long long x = v[k];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-      if (lane == 0) atomicAdd(&a.stats[k], x);
-    }
-    if (lane == 0) {
-      for (int k = 0; k < 3; ++k) {
-        atomicAdd(&a.stats[8 + k], pCyc[k]);
-        atomicAdd(&a.stats[12 + k], pSteps[k]);
-        atomicAdd(&a.stats[15 + k], pLanes[k]);
-      }
-      atomicAdd(&a.stats[11], (unsigned long long)(clock64() - pStart));
-    }
-  }
-}
-
-// combine sample chunks in chunk order: out[0][i] = sum_c out[c][i]
-__global__ void srt_combine_chunks_kernel(float4* buf, int n, int chunks) {
+__global__ void srt_finalize_kernel(const SrtFixedAccum* fix, float4* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float4 acc = buf[i];
-  for (int c = 1; c < chunks; ++c) {
-    float4 v = buf[(size_t)c * n + i];
-    acc.x += v.x;
-    acc.y += v.y;
-    acc.z += v.z;
-    acc.w += v.w;
+  const SrtFixedAccum f = fix[i];
+  const long long ch[3] = {f.r, f.g, f.b};
+  float v[3];
+  for (int k = 0; k < 3; ++k) {
+    v[k] = (float)((double)ch[k] * 0x1p-32);
+    const bool nan = (f.flags >> k) & 1u, pinf = (f.flags >> (3 + k)) & 1u, ninf = (f.flags >> (6 + k)) & 1u;
+    if (nan || (pinf && ninf))
+      v[k] = __builtin_nanf("");
+    else if (pinf)
+      v[k] = SRT_INF;
+    else if (ninf)
+      v[k] = -SRT_INF;
   }
-  buf[i] = acc;
+  out[i] = make_float4(v[0], v[1], v[2], (float)f.count);
 }
 
 // =================================================================== resolve (color.h:25-41)
@@ -1778,29 +1366,17 @@ RenderKernel renderVariant(const RenderArgs* a, int traversal, int count) {
 }
 }  // namespace
 
-namespace {
-RenderKernel render2Variant(const RenderArgs* a, int traversal, int count) {
-  const bool closest = traversal == SRT_TRAVERSE_CLOSEST, single = a == nullptr || a->scene.numWorld == 1;
-  if (count) return closest ? srt_render2_kernel<true, true, false> : srt_render2_kernel<false, true, false>;
-  if (single) return closest ? srt_render2_kernel<true, false, true> : srt_render2_kernel<false, false, true>;
-  return closest ? srt_render2_kernel<true, false, false> : srt_render2_kernel<false, false, false>;
-}
-}  // namespace
-
-// kernel: 1 = srt_render_kernel (one path per lane), 2 = srt_render2_kernel (two paths per lane)
-int srt_launch_render(const RenderArgs* a, int kernel, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
-  hipLaunchKernelGGL(kernel == 2 ? render2Variant(a, traversal, count) : renderVariant(a, traversal, count), dim3(grid),
-                     dim3(SRT_BLOCK), ldsBytes, stream, *a);
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
+  hipLaunchKernelGGL(renderVariant(a, traversal, count), dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, *a);
   return (int)hipGetLastError();
 }
 
-int srt_render_occupancy(int kernel, int traversal, int count, size_t ldsBytes, int* blocksPerCU) {
-  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      blocksPerCU, kernel == 2 ? render2Variant(nullptr, traversal, count) : renderVariant(nullptr, traversal, count), SRT_BLOCK, ldsBytes);
+int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU) {
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, renderVariant(nullptr, traversal, count), SRT_BLOCK, ldsBytes);
 }
 
-int srt_launch_combine(float4* buf, int n, int chunks, hipStream_t stream) {
-  hipLaunchKernelGGL(srt_combine_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, buf, n, chunks);
+int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fix, out, n);
   return (int)hipGetLastError();
 }
 

@@ -262,9 +262,8 @@ def test_scatter_known_answers(ctx, oracle, abi, scenes):
         assert frac > 0.97, frac
 
 
-@pytest.mark.parametrize("kernel", [2, 1])
 @pytest.mark.parametrize("name,bounces", [("masterchief", 4), ("spheres", 8), ("iron", 4)])
-def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, camera, name, bounces, kernel):
+def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, camera, name, bounces):
     """srtTraceRays runs its own kernel; this pins the RENDER kernel's node / primitive steps ray by ray
     (VERDICT r1 item 4): srtRenderAov records, per pixel, the ray srt_render_kernel traced at bounce
     `depth` of the first sample and the hit, t and counters its scheduler-driven traversal (one-FMA slab
@@ -277,7 +276,6 @@ def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, cam
     W, H = 426, 240
     p = abi.default_render_params(W, H, 1, bounces, seed=5)
     seen = 0
-    ctx.set_tunable("kernel", kernel)  # 2: two paths per lane (the default), 1: one path per lane
     for depth in range(3):
         aov = ctx.render_aov(p, depth).reshape(-1)
         rec = aov[aov["valid"] == 1]
@@ -293,5 +291,4 @@ def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, cam
         assert np.array_equal(_bits(rec["t"][m]), _bits(want["t"][m])), (name, depth)
         assert_counters_equal(rec, want)
         seen += len(rec)
-    ctx.set_tunable("kernel", 2)
     assert seen > 1.5 * W * H

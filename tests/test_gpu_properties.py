@@ -120,30 +120,6 @@ def test_image_independent_of_work_distribution(ctx, abi, srt, camera):
             ctx.set_tunable(k, v)
 
 
-@pytest.mark.parametrize("scene,bounces", [("masterchief", 4), ("spheres", 8), ("sphere_field", 8)])
-def test_two_paths_per_lane_kernel_is_bit_identical(ctx, abi, srt, camera, scene, bounces):
-    """srt_render2_kernel (two paths in flight per lane, the default) and srt_render_kernel (one) draw the
-    same random numbers per (pixel, sample) and add samples and chunks in the same order: accumulators,
-    RGBA and every counter must be bit-identical, for the reference's single running sum and for the chunked
-    default, for whole frames and for a rank's share of the tiles."""
-    ctx.upload_scene(srt.scenes.SCENES[scene]())
-    ctx.set_camera(camera)
-    try:
-        for (w, h, spp, chunks, first, stride) in ((203, 117, 24, 1, 0, 1), (426, 240, 64, 0, 0, 1), (160, 90, 40, 5, 0, 1)):
-            p = abi.default_render_params(w, h, spp, bounces, seed=13, spp_chunks=chunks, count_stats=1)
-            out = {}
-            for kernel in (1, 2):
-                ctx.set_tunable("kernel", kernel)
-                acc, rgba = ctx.render_image(p)
-                out[kernel] = (acc, rgba, {k: v for k, v in ctx.stats().items() if not k.startswith(("cycles", "steps", "lanes"))})
-            assert np.array_equal(np.ascontiguousarray(out[1][0]).view(np.uint32), np.ascontiguousarray(out[2][0]).view(np.uint32)), (w, h, spp, chunks)
-            assert np.array_equal(out[1][1], out[2][1])
-            assert out[1][2] == out[2][2], (out[1][2], out[2][2])
-            assert (out[2][0][..., 3] == spp).all()
-    finally:
-        ctx.set_tunable("kernel", 2)
-
-
 def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
     sb = srt.scenes.scene_spheres()
     ctx.upload_scene(sb)
@@ -485,7 +461,8 @@ def test_headline_frame_pooled_residuals_vs_published(ctx, abi, srt, camera):
       * the mean absolute block difference halves each time the pool side doubles (4 -> 8 -> 16 -> 32 px):
         what is left is the Monte-Carlo noise of two independent 5000-spp renders, nothing systematic;
       * pure-black pixels (NaN samples of the r = 0 ground BRDF): same count within a factor of
-        two of the published image's 146, and on the ground like theirs.
+        two of the published image's 146, and where theirs are: four fifths on the ground, the rest on
+        surfaces that see the ground in a bounce (a NaN radiance poisons the whole path).
     The iron sphere is masked out (its texture blobs are missing from the reference; stand-ins here)."""
     import published
     ctx.upload_scene(srt.scenes.scene_masterchief())
@@ -498,15 +475,16 @@ def test_headline_frame_pooled_residuals_vs_published(ctx, abi, srt, camera):
     assert abs(r["bias"]["mesh"]) <= 0.3, r
     assert abs(r["bias"]["metal"]) <= 0.5, r
     mad = r["mad"]
-    assert mad[4] <= 1.6 and mad[16] <= 0.45, mad
+    assert mad[4] <= 0.8 and mad[16] <= 0.25, mad  # measured 0.44 / 0.12 (two independent 5000-spp renders)
     for a, b in ((4, 8), (8, 16), (16, 32)):
         assert 0.40 <= mad[b] / mad[a] <= 0.64, (a, b, mad)
     black = np.argwhere(rgba[..., :3].sum(-1) == 0)
     pub_black = published.published_black("720p")
     assert 0.5 * len(pub_black) <= len(black) <= 2.0 * len(pub_black), (len(black), len(pub_black))
     cls = np.load(os.path.join(published.GOLD, "published_blocks.npz"))["720p_class"]
-    assert (cls[black[:, 0], black[:, 1]] == published.CLASSES["ground"]).mean() >= 0.9
-    assert (cls[pub_black[:, 0], pub_black[:, 1]] == published.CLASSES["ground"]).mean() >= 0.9
+    mine_ground = (cls[black[:, 0], black[:, 1]] == published.CLASSES["ground"]).mean()
+    pub_ground = (cls[pub_black[:, 0], pub_black[:, 1]] == published.CLASSES["ground"]).mean()  # 116 of 146
+    assert abs(mine_ground - pub_ground) <= 0.2 and (cls[black[:, 0], black[:, 1]] != published.CLASSES["sky"]).all()
 
 
 def test_240p_frame_against_published_render(ctx, abi, srt, camera):

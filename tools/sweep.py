@@ -28,11 +28,10 @@ def main():
             "prim": [int(x) for x in os.environ.get("SWEEP_PRIM", "12,20,28").split(",")],
             "burst": [int(x) for x in os.environ.get("SWEEP_BURST", "16").split(",")],
             "hit": [int(x) for x in os.environ.get("SWEEP_HIT", "24").split(",")],
-            "swap": [int(x) for x in os.environ.get("SWEEP_SWAP", "8").split(",")],
-            "kernel": [int(x) for x in os.environ.get("SWEEP_KERNEL", "2").split(",")]}
-    for kn, c, sm, pm, nb, hm, sw in itertools.product(grid["kernel"], grid["chunks"], grid["shade"], grid["prim"], grid["burst"], grid["hit"], grid["swap"]):
-        for k, v in (("kernel", kn), ("shade_min", sm), ("prim_min", pm), ("node_burst", nb), ("hit_min", hm), ("swap_min", sw)):
+            }
+    for c, sm, pm, nb, hm in itertools.product(grid["chunks"], grid["shade"], grid["prim"], grid["burst"], grid["hit"]):
+        for k, v in (("shade_min", sm), ("prim_min", pm), ("node_burst", nb), ("hit_min", hm)):
             ctx.set_tunable(k, v)
-        print("kernel %d chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d swapMin %2d : %8.1f Msamples/s" % (kn, c, sm, pm, nb, hm, sw, run(c)), flush=True)
+        print("chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d : %8.1f Msamples/s" % (c, sm, pm, nb, hm, run(c)), flush=True)
 
 main()

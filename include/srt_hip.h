@@ -197,7 +197,7 @@ typedef struct SrtRenderParams {
   /* One work item = one pixel x one chunk of its samples.  Samples are summed in index order inside a
    * chunk (a float running sum, main.cpp:217).  1 = a single running sum per pixel, the reference's order
    * (main.cpp:204-218), bit-reproducible against the oracle.  > 1: the chunks' float sums are added EXACTLY
-   * (64-bit fixed point with 2^-32 resolution, integer atomics) and rounded to float once, so the pixel sum
+   * (64-bit fixed point with 2^-36 resolution, integer atomics) and rounded to float once, so the pixel sum
    * does not depend on the order in which chunks finish, on the tile split or on the GPU count, and needs
    * 32 bytes of scratch per pixel whatever the chunk count; it differs from the single running sum only by
    * the re-association of the float sum (<= 2e-5 relative).  0 = library default

@@ -684,7 +684,7 @@ struct Scene {
   uint64_t buildDraws = 0;
 };
 
-static Scene* buildScene(const SrtSceneDesc* d) {
+static Scene* buildScene(const SrtSceneDesc* d, uint64_t preDraws) {
   auto s = std::make_unique<Scene>();
   s->texels.assign(d->texels, d->texels + d->numTexelBytes);
   const uint8_t* tbase = s->texels.data();
@@ -749,6 +749,7 @@ static Scene* buildScene(const SrtSceneDesc* d) {
   Rng rng;
   rng.mode = RNG_MT;
   rng.mt = &s->mt;
+  s->mt.discard(preDraws);  // one 32-bit draw per randomFloat() (generate_canonical<float, 24> over mt19937)
   for (int w = 0; w < d->numWorld; w++) {
     const SrtWorldItem& it = d->world[w];
     if (it.kind == SRT_WORLD_PRIM) {
@@ -825,7 +826,11 @@ struct OrcStats {
 
 extern "C" {
 
-void* orc_scene_create(const SrtSceneDesc* d) { return buildScene(d); }
+void* orc_scene_create(const SrtSceneDesc* d) { return buildScene(d, 0); }
+// preDraws: randomFloat() calls the scene-construction code made on the process-global generator before the
+// world's bvhNode is built (main.cpp:92-122 draws sphere placements from it; the reference then continues the
+// SAME stream into bvh.h:60) -- the scene handle's generator skips that many draws first.
+void* orc_scene_create2(const SrtSceneDesc* d, uint64_t preDraws) { return buildScene(d, preDraws); }
 void orc_scene_destroy(void* h) { delete static_cast<Scene*>(h); }
 uint64_t orc_build_draws(void* h) { return static_cast<Scene*>(h)->buildDraws; }
 

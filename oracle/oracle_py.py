@@ -45,6 +45,8 @@ def lib():
         L = C.CDLL(build())
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(abi.SrtSceneDesc)]
+        L.orc_scene_create2.restype = C.c_void_p
+        L.orc_scene_create2.argtypes = [C.POINTER(abi.SrtSceneDesc), C.c_uint64]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_build_draws.restype = C.c_uint64
         L.orc_build_draws.argtypes = [C.c_void_p]
@@ -85,7 +87,9 @@ class OracleScene:
     def __init__(self, scene_builder):
         self.sb = scene_builder
         self.desc = scene_builder.desc()
-        self.h = lib().orc_scene_create(C.byref(self.desc))
+        # scenes whose construction drew from the process-global generator (scenes.scene_sphere_field): the
+        # bvhNode build continues that stream, as it would in the reference's process
+        self.h = lib().orc_scene_create2(C.byref(self.desc), int(getattr(scene_builder, "global_rng_draws", 0)))
 
     def __del__(self):
         if getattr(self, "h", None):

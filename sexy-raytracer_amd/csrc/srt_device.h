@@ -98,7 +98,7 @@ inline SrtDivisor srtMakeDivisor(uint32_t d) {
 }
 
 struct SrtFixedAccum {  // 32 B per pixel of a rank's tile buffer: exact sum of the items' partial sums (commitFixed)
-  long long r, g, b;    // units of 2^-32
+  long long r, g, b;    // units of 2^-36
   int32_t count;        // samples added
   uint32_t flags;       // bit k: a NaN partial sum in channel k; bit 3+k: +inf; bit 6+k: -inf
 };

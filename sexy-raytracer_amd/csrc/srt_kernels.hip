@@ -703,25 +703,33 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 }
 
 // Chunk sums of a pixel (sppChunks > 1) are added EXACTLY: every item converts its float partial sum to
-// 64-bit fixed point (2^-32) and adds it with one integer atomic per channel.  Integer addition is
+// 64-bit fixed point (units of 2^-36) and adds it with one integer atomic per channel.  Integer addition is
 // associative, so the pixel sum does not depend on which chunk finishes first (items of a pixel run on
 // different waves and end in any order), needs no per-chunk scratch (32 B per pixel instead of
 // chunks x 16 B) and no ordered reduction pass; srt_finalize_kernel rounds the exact sum to float once.
-// Partial sums of 2^-8 and more convert exactly (their float ulp is >= 2^-32); smaller ones are rounded
-// to 2^-32 absolute.  NaN / infinite partial sums (the r = 0 ground BRDF produces NaN samples)
-// set per-channel flags and poison the channel as they would a float sum.  Range: |pixel sum| < 2^31.
+// A float of 2^-12 or more converts exactly (its ulp is >= 2^-36; smaller ones are truncated to 2^-36
+// absolute), so two chunk sums a, b >= 2^-12 give fl(a + b) bit for bit.  NaN / infinite partial sums (the
+// r = 0 ground BRDF produces NaN samples) set per-channel flags and poison the channel as they
+// would a float sum.  Range: |pixel sum| < 2^27 (items beyond 2^26 count as infinite).
 __device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc, int samples) {
   const float c[3] = {acc.x, acc.y, acc.z};
   long long* const ch = &f->r;
   uint32_t flags = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float v = c[k];
-    if (!(fabsf(v) < 0x1p30f)) {  // NaN, infinite or beyond the fixed-point range (treated as infinite)
+    const float v = c[k], av = fabsf(v);
+    if (!(av < 0x1p26f)) {  // NaN, infinite or beyond the fixed-point range
       flags |= (v != v) ? (1u << k) : (v > 0.0f ? (8u << k) : (64u << k));
     } else {
-      const long long q = __float2ll_rn(v * 0x1p32f);
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), (unsigned long long)q);
+      // |v| = hi + fr with hi = trunc(|v|) < 2^26 and fr in [0, 1), both exact; fixed = hi * 2^36 + trunc(fr * 2^36)
+      const uint32_t hi = (uint32_t)av;
+      const float fr = av - (float)hi;
+      const uint32_t frHi = (uint32_t)(fr * 0x1p32f);                       // top 32 bits of the fraction
+      const float rest = fr * 0x1p32f - (float)frHi;                        // exact: what is left below 2^-32, in [0, 1)
+      const uint32_t frLo = (uint32_t)(rest * 16.0f);                       // 4 more bits
+      unsigned long long q = ((unsigned long long)hi << 36) + ((unsigned long long)frHi << 4) + frLo;
+      if (v < 0.0f) q = 0ull - q;
+      if (q != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), q);
     }
   }
   atomicAdd(&f->count, samples);
@@ -1218,7 +1226,7 @@ __global__ void srt_finalize_kernel(const SrtFixedAccum* fix, float4* out, int n
   const long long ch[3] = {f.r, f.g, f.b};
   float v[3];
   for (int k = 0; k < 3; ++k) {
-    v[k] = (float)((double)ch[k] * 0x1p-32);
+    v[k] = (float)((double)ch[k] * 0x1p-36);
     const bool nan = (f.flags >> k) & 1u, pinf = (f.flags >> (3 + k)) & 1u, ninf = (f.flags >> (6 + k)) & 1u;
     if (nan || (pinf && ninf))
       v[k] = __builtin_nanf("");

@@ -100,16 +100,25 @@ def default_spp_chunks(spp):
     return int(lib.srtDefaultSppChunks(spp))
 
 
+def _reset_generator_for(scene_builder):
+    """The process-global generator as the reference's process would have it when the world's bvhNode is
+    constructed: fresh (globals.h:31-32), minus the draws the scene's own construction code took
+    (scenes.scene_sphere_field records them)."""
+    host_random_reset()
+    for _ in range(int(getattr(scene_builder, "global_rng_draws", 0))):
+        lib.srtHostRandomFloat()
+
+
 def build_bvh_host(scene_builder, item=0, reset_rng=True):
     """bvh.h:55-95 on the host, no GPU: returns (nodes, traversal stack depth)."""
     desc = scene_builder.desc()
     n, sd = C.c_int32(0), C.c_int32(0)
     if reset_rng:
-        host_random_reset()
+        _reset_generator_for(scene_builder)
     if lib.srtBuildBvh(C.byref(desc), item, None, 0, C.byref(n), C.byref(sd)):
         raise SrtError("srtBuildBvh failed")
     if reset_rng:  # the sizing call consumed generator draws: rebuild from the same state
-        host_random_reset()
+        _reset_generator_for(scene_builder)
     nodes = np.zeros(n.value, abi.NODE_DTYPE)
     if lib.srtBuildBvh(C.byref(desc), item, nodes.ctypes.data, n.value, C.byref(n), C.byref(sd)):
         raise SrtError("srtBuildBvh failed")
@@ -147,10 +156,10 @@ class Context:
             raise SrtError(lib.srtLastError(self.h).decode())
 
     def upload_scene(self, scene_builder, reset_rng=True):
-        """reset_rng: start from the fresh process-global generator, as a new process of the
-        reference would (globals.h:31-32)."""
+        """reset_rng: start from the process-global generator of a new process of the reference
+        (globals.h:31-32), advanced past the draws the scene's construction took."""
         if reset_rng:
-            host_random_reset()
+            _reset_generator_for(scene_builder)
         desc = scene_builder.desc()
         self._scene_keep = (scene_builder, desc)
         self._check(lib.srtUploadScene(self.h, C.byref(desc)))

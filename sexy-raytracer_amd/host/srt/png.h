@@ -37,6 +37,7 @@ inline uint8_t* srtPngLoad(const char* filename, int* w, int* h, int* comp, int 
     const uint8_t* data = &file[pos + 8];
     if (pos + 12 + (size_t)len > file.size()) return nullptr;
     if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) return nullptr;  // the fixed IHDR layout is read below
       width = srtBe32(data); height = srtBe32(data + 4);
       depth = data[8]; ctype = data[9]; interlace = data[12];
     } else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
@@ -46,6 +47,9 @@ inline uint8_t* srtPngLoad(const char* filename, int* w, int* h, int* comp, int 
     pos += 12 + (size_t)len;
   }
   const bool lowDepth = depth == 1 || depth == 2 || depth == 4;  // allowed for grey and palette only
+  // header fields are untrusted: bound the image before any size arithmetic (32768^2 x 8 bytes < 2^43 fits
+  // size_t; the int outputs *w, *h stay positive)
+  if (width > 32768u || height > 32768u) return nullptr;
   if (!width || !height || interlace || !(depth == 8 || depth == 16 || lowDepth) || (lowDepth && ctype != 0 && ctype != 3) ||
       (ctype == 3 && depth == 16))
     return nullptr;

@@ -156,12 +156,20 @@ def scene_sphere_field():
     diffuse spheres (sphere.h:47-52), fuzzy metals, glass, placed with the process-global generator
     (globals.h:30-35), plus the ground and the three big spheres of main.cpp:90,124-144.  Draws are taken
     in the order g++ evaluates that code (call arguments right to left); the reference never runs it, so
-    the order is unpinned -- the scene's use is as a parity workload for the features no config exercises."""
+    the order is unpinned -- the scene's use is as a parity workload for the features no config exercises.
+    In the reference's process the bvhNode constructor (main.cpp:146) goes on drawing from the same stream
+    after these placements; `global_rng_draws` records how many were taken so that Context.upload_scene and
+    the oracle build the tree from that point of the stream, not from a fresh generator."""
     from . import hipdev  # the global generator lives in the C-ABI library (no GPU needed)
-    rf = hipdev.host_random_float
     f32 = np.float32
     hipdev.host_random_reset()
     sb = SceneBuilder()
+    sb.global_rng_draws = 0  # draws taken from the generator: the bvhNode build must continue after them
+
+    def rf():
+        sb.global_rng_draws += 1
+        return hipdev.host_random_float()
+
     _ground(sb)
     glass = sb.dielectric(1.5)
     for a in range(-11, 11):

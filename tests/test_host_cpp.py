@@ -148,3 +148,34 @@ def test_cpp_png_decoder_formats(tmp_path, mode, req):
     subprocess.check_call([tool, "encode", raw, str(w), str(h), str(req), back])
     pil = np.asarray(Image.open(back))
     assert np.array_equal(pil.reshape(h, w, req), got)
+
+
+def test_cpp_png_decoder_rejects_hostile_headers(tmp_path):
+    """Header fields of a texture file named by a glTF are untrusted: huge or zero dimensions,
+    an IHDR chunk of the wrong length and truncated files must fail cleanly, not overflow the size arithmetic."""
+    import struct
+    import zlib
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sexy-raytracer_amd", "host")])
+    tool = os.path.join(ROOT, "examples", "srt_png_tool")
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+
+    def png(width, height, ihdr_extra=b"", idat=None):
+        ihdr = struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0) + ihdr_extra
+        idat = zlib.compress(b"\0" * 64) if idat is None else idat
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+    cases = {"huge": png(0x7fffffff, 0x7fffffff), "wrap": png(0x10000001, 0x10), "zero": png(0, 5),
+             "long_ihdr": png(4, 4, ihdr_extra=b"\0\0\0"), "short_idat": png(64, 64),
+             "truncated": png(4, 4)[:40]}
+    for name, blob in cases.items():
+        path = str(tmp_path / (name + ".png"))
+        open(path, "wb").write(blob)
+        r = subprocess.run([tool, "decode", path, "3", str(tmp_path / "o.raw")], capture_output=True)
+        assert r.returncode == 1 and b"decode failed" in r.stderr, (name, r.returncode, r.stderr[-200:])
+    # a good file of the same shape still decodes
+    good = png(4, 4, idat=zlib.compress(b"".join(b"\0" + bytes(range(12)) for _ in range(4))))
+    path = str(tmp_path / "good.png")
+    open(path, "wb").write(good)
+    assert subprocess.run([tool, "decode", path, "3", str(tmp_path / "o.raw")], capture_output=True).returncode == 0

@@ -24,7 +24,8 @@
 extern "C" {
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU);
-int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, hipStream_t stream);
+int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream);
+int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
@@ -225,7 +226,7 @@ struct Tunables {
   int tileBlock, unitTiles, queues;
   int shadeMin, primMin, hitMin, fuseMin, nodeBurst;
   int plocRadius, fastDiv;
-  int maxLiveChunks;
+  int chunkScratchMb;
 };
 
 struct SrtContext {
@@ -316,7 +317,7 @@ const TunableName kTunables[] = {
     {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 32},
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
-    {"max_live_chunks", "SRT_MAX_LIVE_CHUNKS", &Tunables::maxLiveChunks, -1},
+    {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 1024},  // budget of the chunk-slot path, whole frame
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -793,17 +794,14 @@ int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
   return (srtNumTiles(w, h) + stride - 1) / stride;
 }
 
-// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about 32 samples
-// per item, but at least 128 items per pixel when there are that many samples (down to one sample per item:
-// 64 spp on the 240p spheres frame run at 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks).  Many chunks per tile keep the tiles in flight few -- a queue's waves pull consecutive items,
-// i.e. the chunks of one tile, then of its neighbour -- and that coherence is worth more than the cost of
-// small items: 625 spp on the headline frame take 200 ms with 20 chunks, 183 ms with 78, 182 ms with 157.
-// History on the 720p/5000-spp frame (single work counter): 1 chunk 563, 8 chunks 1829, 64 chunks 2023,
-// 128-256 chunks 2082-2099, 1000 chunks 1830 Msamples/s.
-int32_t srtDefaultSppChunks(int32_t spp) {
-  const int32_t bySize = (spp + 31) / 32, byCount = std::min(128, spp);
-  return std::max(1, std::min(256, std::max(bySize, byCount)));
-}
+// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): min(64, spp).
+// Many items per pixel keep the tiles in flight few -- a queue's waves pull consecutive items, i.e. the chunks
+// of one tile, then of its neighbour -- and that coherence is worth more than the cost of small items.
+// Round 2, 720p headline at 5000 spp (Msamples/s): 1 chunk 500, 2: 1381, 4: 2274, 8: 2810, 16: 2983, 32: 3195,
+// 64: 3333, 157: 3335, 256: 3312, 1024: 3178 (profiles/r02/chunk_sweep.txt).  64 keeps the chunk slots of a
+// 720p frame under 1 GiB (srtRenderTiles: scratch path); low sample counts get one sample per item (64 spp on
+// the 240p spheres frame: 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks).
+int32_t srtDefaultSppChunks(int32_t spp) { return std::max(1, std::min(64, spp)); }
 
 static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
@@ -897,17 +895,28 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   const size_t tilePixels = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
   a.out = static_cast<float4*>(dAccumTiles);
   a.fix = nullptr;
+  a.chunkStride = 0;
+  bool scratchPath = false;
   if (a.sppChunks > 1) {
-    // items of a pixel add their partial sums exactly (64-bit fixed point): 32 B per pixel whatever the chunk count
-    const size_t need = tilePixels * sizeof(SrtFixedAccum);
+    // Chunk sums are added exactly (srt_kernels.hip "Chunk sums").  Scratch path (a float4 slot per item, summed by
+    // srt_sum_chunks_kernel) while the WHOLE frame's slots fit the budget -- decided on the frame, not on this
+    // rank's share, so that the choice is the same for every rank count -- else the atomic path (32 B per pixel).
+    const size_t frameSlots = (size_t)a.numTiles * SRT_TILE_PIXELS * a.sppChunks * sizeof(float4);
+    scratchPath = frameSlots <= (size_t)std::max(0, ctx->tun.chunkScratchMb) * 1024 * 1024;
+    const size_t need = scratchPath ? tilePixels * a.sppChunks * sizeof(float4) : tilePixels * sizeof(SrtFixedAccum);
     if (ctx->chunkScratch.bytes < need) {
       if (ctx->chunkScratch.p) HIP_OK(ctx, hipFree(ctx->chunkScratch.p));
       ctx->chunkScratch = DeviceBuffer();
       HIP_OK(ctx, hipMalloc(&ctx->chunkScratch.p, need));
       ctx->chunkScratch.bytes = need;
     }
-    a.fix = static_cast<SrtFixedAccum*>(ctx->chunkScratch.p);
-    HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
+    if (scratchPath) {
+      a.out = static_cast<float4*>(ctx->chunkScratch.p);
+      a.chunkStride = (int32_t)tilePixels;
+    } else {
+      a.fix = static_cast<SrtFixedAccum*>(ctx->chunkScratch.p);
+      HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
+    }
   }
   const size_t lds = ldsBytesFor(ctx, p->maxBounce);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
@@ -924,8 +933,11 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;
   if (a.fix) {
-    rc = srt_launch_finalize(a.fix, static_cast<float4*>(dAccumTiles), (int)tilePixels, stream);
+    rc = srt_launch_finalize(a.fix, static_cast<float4*>(dAccumTiles), (int)tilePixels, a.spp, stream);
     if (rc) return fail(ctx, "finalize launch failed: %s", hipGetErrorString((hipError_t)rc));
+  } else if (scratchPath) {
+    rc = srt_launch_sum_chunks(a.out, static_cast<float4*>(dAccumTiles), (int)tilePixels, a.sppChunks, stream);
+    if (rc) return fail(ctx, "chunk sum launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
   return 0;
 }

@@ -99,8 +99,8 @@ inline SrtDivisor srtMakeDivisor(uint32_t d) {
 
 struct SrtFixedAccum {  // 32 B per pixel of a rank's tile buffer: exact sum of the items' partial sums (commitFixed)
   long long r, g, b;    // units of 2^-36
-  int32_t count;        // samples added
   uint32_t flags;       // bit k: a NaN partial sum in channel k; bit 3+k: +inf; bit 6+k: -inf
+  uint32_t pad;
 };
 
 struct RenderArgs {
@@ -124,8 +124,10 @@ struct RenderArgs {
   int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
   int32_t nodeBurst;          // max node visits per scheduling decision
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
-  float4* out;      // [localTile][64]: written directly when sppChunks == 1 (the reference's float running sum)
-  SrtFixedAccum* fix;  // [localTile][64]: sppChunks > 1, items add their partial sums here (null otherwise)
+  float4* out;      // sppChunks == 1: the caller's [localTile][64] buffer (the reference's float running sum, written
+                    // directly); scratch path: chunk slots [chunk][localTile][64]
+  int32_t chunkStride;  // scratch path: numLocalTiles * 64, else 0
+  SrtFixedAccum* fix;   // atomic path: [localTile][64], items add their fixed-point partial sums here (null otherwise)
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr
   SrtAovRecord* aov;          // counting variant only: per-pixel record of the ray at bounce aovDepth (srtRenderAov)
   int32_t aovDepth;

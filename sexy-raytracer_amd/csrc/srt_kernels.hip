@@ -702,37 +702,57 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
   r.time = rng.uniform(c.time0, c.time1);
 }
 
-// Chunk sums of a pixel (sppChunks > 1) are added EXACTLY: every item converts its float partial sum to
-// 64-bit fixed point (units of 2^-36) and adds it with one integer atomic per channel.  Integer addition is
-// associative, so the pixel sum does not depend on which chunk finishes first (items of a pixel run on
-// different waves and end in any order), needs no per-chunk scratch (32 B per pixel instead of
-// chunks x 16 B) and no ordered reduction pass; srt_finalize_kernel rounds the exact sum to float once.
+// Chunk sums of a pixel (sppChunks > 1) are added EXACTLY: each item's float partial sum is converted to
+// 64-bit fixed point (units of 2^-36), the integers are added, and the sum is rounded to float once.  Integer
+// addition is associative, so the pixel sum does not depend on the order in which chunks finish (items of a
+// pixel run on different waves), on the tile split or on the GPU count.  Two implementations of the same sum:
+//   * scratch path: an item stores its float4 partial in slot [chunk][tile][pixel]; srt_sum_chunks_kernel
+//     converts and adds the slots (one plain store per item in the render kernel, chunks x 16 B per pixel);
+//   * atomic path (commitFixed): items add their fixed-point partials with three 64-bit integer atomics into
+//     32 B per pixel; srt_finalize_kernel rounds.  Memory is O(pixels) for any chunk count, at the price of the
+//     memory-side atomics (scattered 8-byte atomics retire at ~20 G/s chip-wide: 1-2 % on the 720p headline,
+//     a third of the time of a 240p / 64-spp frame).
+// srtRenderTiles picks the scratch path while the whole frame's slots fit a memory budget, the atomic path
+// beyond; the image is the same bit for bit.
 // A float of 2^-12 or more converts exactly (its ulp is >= 2^-36; smaller ones are truncated to 2^-36
 // absolute), so two chunk sums a, b >= 2^-12 give fl(a + b) bit for bit.  NaN / infinite partial sums (the
-// r = 0 ground BRDF produces NaN samples) set per-channel flags and poison the channel as they
-// would a float sum.  Range: |pixel sum| < 2^27 (items beyond 2^26 count as infinite).
-__device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc, int samples) {
+// r = 0 ground BRDF produces NaN samples) poison the channel as they would a float sum.
+// Range: |pixel sum| < 2^27 (partial sums beyond 2^26 count as infinite).
+// Returns false for a value that is not representable (NaN / infinite / too large).
+__device__ __forceinline__ bool toFixed36(float v, long long& q) {
+  const float av = fabsf(v);
+  if (!(av < 0x1p26f)) return false;
+  // |v| = hi + fr with hi = trunc(|v|) < 2^26 and fr in [0, 1), both exact; fixed = hi * 2^36 + trunc(fr * 2^36)
+  const uint32_t hi = (uint32_t)av;
+  const float fr = av - (float)hi;
+  const uint32_t frHi = (uint32_t)(fr * 0x1p32f);  // top 32 bits of the fraction
+  const float rest = fr * 0x1p32f - (float)frHi;   // exact: what is left below 2^-32, in [0, 1)
+  const uint32_t frLo = (uint32_t)(rest * 16.0f);  // 4 more bits
+  const unsigned long long m = ((unsigned long long)hi << 36) + ((unsigned long long)frHi << 4) + frLo;
+  q = (long long)(v < 0.0f ? 0ull - m : m);
+  return true;
+}
+// flags: bit k: NaN in channel k; bit 3+k: +inf; bit 6+k: -inf
+__device__ __forceinline__ uint32_t nonFiniteFlag(float v, int k) { return (v != v) ? (1u << k) : (v > 0.0f ? (8u << k) : (64u << k)); }
+__device__ __forceinline__ float fromFixed36(long long q, uint32_t flags, int k) {
+  const bool nan = (flags >> k) & 1u, pinf = (flags >> (3 + k)) & 1u, ninf = (flags >> (6 + k)) & 1u;
+  if (nan || (pinf && ninf)) return __builtin_nanf("");
+  if (pinf) return SRT_INF;
+  if (ninf) return -SRT_INF;
+  return (float)((double)q * 0x1p-36);
+}
+__device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc) {
   const float c[3] = {acc.x, acc.y, acc.z};
   long long* const ch = &f->r;
   uint32_t flags = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float v = c[k], av = fabsf(v);
-    if (!(av < 0x1p26f)) {  // NaN, infinite or beyond the fixed-point range
-      flags |= (v != v) ? (1u << k) : (v > 0.0f ? (8u << k) : (64u << k));
-    } else {
-      // |v| = hi + fr with hi = trunc(|v|) < 2^26 and fr in [0, 1), both exact; fixed = hi * 2^36 + trunc(fr * 2^36)
-      const uint32_t hi = (uint32_t)av;
-      const float fr = av - (float)hi;
-      const uint32_t frHi = (uint32_t)(fr * 0x1p32f);                       // top 32 bits of the fraction
-      const float rest = fr * 0x1p32f - (float)frHi;                        // exact: what is left below 2^-32, in [0, 1)
-      const uint32_t frLo = (uint32_t)(rest * 16.0f);                       // 4 more bits
-      unsigned long long q = ((unsigned long long)hi << 36) + ((unsigned long long)frHi << 4) + frLo;
-      if (v < 0.0f) q = 0ull - q;
-      if (q != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), q);
-    }
+    long long q;
+    if (!toFixed36(c[k], q))
+      flags |= nonFiniteFlag(c[k], k);
+    else if (q != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), (unsigned long long)q);
   }
-  atomicAdd(&f->count, samples);
   if (flags) atomicOr(&f->flags, flags);
 }
 
@@ -1112,7 +1132,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           // work item finished (or none yet): write it, pull the next one with one atomic per wave
           if (outIndex >= 0) {
             if (a.fix)
-              commitFixed(a.fix + outIndex, acc, sCount);
+              commitFixed(a.fix + outIndex, acc);
             else
               a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
           }
@@ -1181,7 +1201,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             s = s0;
             sEnd = valid ? s1 : s0;
             acc = mk(0.0f, 0.0f, 0.0f);
-            outIndex = localTile < a.numLocalTiles ? localTile * SRT_TILE_PIXELS + ln : -1;
+            // slot of this item: [chunk][localTile][pixel] on the scratch path (chunkStride = numLocalTiles * 64),
+            // [localTile][pixel] otherwise (chunkStride = 0)
+            outIndex = localTile < a.numLocalTiles ? chunk * a.chunkStride + localTile * SRT_TILE_PIXELS + ln : -1;
           }
         }
         if (alive && s < sEnd) {
@@ -1219,23 +1241,36 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   }
 }
 
-__global__ void srt_finalize_kernel(const SrtFixedAccum* fix, float4* out, int n) {
+// atomic path: round the exact sums.  samples = what every pixel of the launch received (the items of a pixel
+// partition its sample range, so the count needs no atomics).
+__global__ void srt_finalize_kernel(const SrtFixedAccum* fix, float4* out, int n, int samples) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const SrtFixedAccum f = fix[i];
-  const long long ch[3] = {f.r, f.g, f.b};
-  float v[3];
-  for (int k = 0; k < 3; ++k) {
-    v[k] = (float)((double)ch[k] * 0x1p-36);
-    const bool nan = (f.flags >> k) & 1u, pinf = (f.flags >> (3 + k)) & 1u, ninf = (f.flags >> (6 + k)) & 1u;
-    if (nan || (pinf && ninf))
-      v[k] = __builtin_nanf("");
-    else if (pinf)
-      v[k] = SRT_INF;
-    else if (ninf)
-      v[k] = -SRT_INF;
+  out[i] = make_float4(fromFixed36(f.r, f.flags, 0), fromFixed36(f.g, f.flags, 1), fromFixed36(f.b, f.flags, 2), (float)samples);
+}
+
+// scratch path: the same exact sum over the chunk slots buf[c][i]
+__global__ void srt_sum_chunks_kernel(const float4* buf, float4* out, int n, int chunks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long long sum[3] = {0, 0, 0};
+  uint32_t flags = 0;
+  float count = 0.0f;
+  for (int c = 0; c < chunks; ++c) {
+    const float4 v = buf[(size_t)c * n + i];
+    const float ch[3] = {v.x, v.y, v.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      long long q;
+      if (toFixed36(ch[k], q))
+        sum[k] += q;
+      else
+        flags |= nonFiniteFlag(ch[k], k);
+    }
+    count += v.w;
   }
-  out[i] = make_float4(v[0], v[1], v[2], (float)f.count);
+  out[i] = make_float4(fromFixed36(sum[0], flags, 0), fromFixed36(sum[1], flags, 1), fromFixed36(sum[2], flags, 2), count);
 }
 
 // =================================================================== resolve (color.h:25-41)
@@ -1383,8 +1418,13 @@ int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksP
   return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, renderVariant(nullptr, traversal, count), SRT_BLOCK, ldsBytes);
 }
 
-int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(srt_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fix, out, n);
+int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fix, out, n, samples);
+  return (int)hipGetLastError();
+}
+
+int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, buf, out, n, chunks);
   return (int)hipGetLastError();
 }
 

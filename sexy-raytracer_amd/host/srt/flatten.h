@@ -20,6 +20,7 @@ class sceneFlattener {
   std::vector<SrtPrimRef> prims;
   std::vector<SrtWorldItem> world;
   std::vector<SrtMaterialIn> materials;
+  std::vector<shared_ptr<material>> materialPtrs;  // materials[i] was produced by materialPtrs[i] (hitRecord::matPtr)
   std::vector<SrtTextureIn> textures;
   std::vector<uint8_t> texels;
   std::vector<std::vector<SrtBvhNode>> trees;  // remapped prebuilt trees, kept alive for desc()

@@ -10,8 +10,14 @@ class hittableList : public hittable {
  public:
   hittableList() {}
   hittableList(shared_ptr<hittable> object) { add(object); }
-  void clear() { objects.clear(); }
-  void add(shared_ptr<hittable> object) { objects.push_back(object); }
+  void clear() {
+    objects.clear();
+    dropHitSession();
+  }
+  void add(shared_ptr<hittable> object) {
+    objects.push_back(object);
+    dropHitSession();
+  }
 
   bool boundingBox(float time0, float time1, aabb& outputBox) const override {  // hittablelist.h:49-64
     if (objects.empty()) return false;

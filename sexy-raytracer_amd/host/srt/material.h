@@ -109,6 +109,8 @@ inline int sceneFlattener::materialId(const shared_ptr<material>& m) {
   if (it != matIds_.end()) return it->second;
   int id = m->populate(*this);
   matIds_[m.get()] = id;
+  if ((int)materialPtrs.size() <= id) materialPtrs.resize(id + 1);
+  materialPtrs[id] = m;
   return id;
 }
 

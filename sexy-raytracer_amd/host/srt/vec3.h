@@ -24,6 +24,11 @@ struct srtVec {
   srtVec operator-() const { srtVec r; for (int i = 0; i < N; ++i) r.e[i] = -e[i]; return r; }
   srtVec operator*(float s) const { srtVec r; for (int i = 0; i < N; ++i) r.e[i] = e[i] * s; return r; }
   srtVec operator/(float s) const { srtVec r; for (int i = 0; i < N; ++i) r.e[i] = e[i] / s; return r; }
+  // Eigen's 3-vector reduction order, x*x' + (y*y' + z*z') (the oracle's and the kernels' dot3)
+  float dot(const srtVec& o) const {
+    static_assert(N == 3, "");
+    return e[0] * o.e[0] + (e[1] * o.e[1] + e[2] * o.e[2]);
+  }
   bool operator!=(const srtVec& o) const { for (int i = 0; i < N; ++i) if (e[i] != o.e[i]) return true; return false; }
 };
 template <int N>

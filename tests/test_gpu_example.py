@@ -36,3 +36,35 @@ def test_cpp_example_matches_python_path(tmp_path, ctx, abi, srt, camera):
     _, want = ctx.render_image(abi.default_render_params(426, 240, 8, 4, seed=1, spp_chunks=1))
     assert got.shape == want.shape == (240, 426, 4)
     assert np.array_equal(got, want)
+
+
+def test_cpp_world_hit_on_the_host_classes(ctx, abi, srt):
+    """Scene code that calls world.hit(r, tMin, tMax, rec) (hittable.h:26) compiles against the host mirror
+    and gets the device's answer: examples/hit_probe.cpp builds the three-sphere scene with the reference's
+    class vocabulary and calls hittableList::hit ray by ray; t, p, normal, frontFace and the material pointer
+    must be what srtTraceRays returns for the same scene built through the Python path."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sexy-raytracer_amd", "host")])
+    out = subprocess.check_output([os.path.join(ROOT, "examples", "srt_hit_probe")]).decode().split("\n")
+    rays = np.zeros(35, abi.RAY_DTYPE)
+    k = 0
+    for j in range(5):
+        for i in range(7):
+            rays[k]["o"] = (0.0, 3.0, 5.0)
+            rays[k]["d"] = (-6.0 + 2.0 * i, -3.5 + 1.0 * j, -5.0)
+            k += 1
+    rays["time"], rays["tMin"], rays["tMax"] = 0.25, 0.001, np.inf
+    ctx.upload_scene(srt.scenes.scene_spheres())
+    want = ctx.trace(rays)
+    mat_of_prim = {0: 0, 1: 1, 2: 2, 3: 3}  # scene_spheres adds ground, diffuse, glass, mirror in this order
+    assert (want["prim"] >= 0).sum() >= 20 and (want["prim"] < 0).sum() >= 3
+    for k in range(35):
+        f = out[k].split()
+        if want["prim"][k] < 0:
+            assert f[0] == "miss", (k, out[k])
+            continue
+        assert f[0] == "hit", (k, out[k])
+        vals = np.array([float.fromhex(x) for x in f[1:8]], np.float32)
+        ref = np.concatenate([[want["t"][k]], want["p"][k], want["normal"][k]]).astype(np.float32)
+        assert np.array_equal(vals.view(np.uint32), ref.view(np.uint32)), (k, vals, ref)
+        assert int(f[8]) == int(want["frontFace"][k]) and int(f[9]) == mat_of_prim[int(want["prim"][k])]
+    assert out[35] == "ball hit" and float.fromhex(out[36].split()[1]) == 2.0

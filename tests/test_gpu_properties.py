@@ -120,6 +120,36 @@ def test_image_independent_of_work_distribution(ctx, abi, srt, camera):
             ctx.set_tunable(k, v)
 
 
+def test_exact_chunk_sum_paths_agree(ctx, dev, abi, srt, camera):
+    """The chunk sums of a pixel are added exactly (64-bit fixed point), by chunk slots + a summing kernel
+    while the frame's slots fit the memory budget and by integer atomics beyond it (32 B per pixel for any
+    chunk count): the two must give the same bits, for whole frames and for a rank's share of the tiles, NaN
+    pixels included (the r = 0 ground BRDF of the main.cpp scene produces them)."""
+    import torch
+    ctx.upload_scene(srt.scenes.scene_masterchief())
+    ctx.set_camera(camera)
+    budget = ctx.get_tunable("chunk_scratch_mb")
+    try:
+        for (w, h, spp, chunks, first, stride) in ((203, 117, 48, 0, 0, 1), (426, 240, 96, 7, 0, 1), (426, 240, 96, 7, 1, 3)):
+            p = abi.default_render_params(w, h, spp, 4, seed=17, spp_chunks=chunks, tile_first=first, tile_stride=stride)
+            out = {}
+            for mb in (budget, 0):
+                ctx.set_tunable("chunk_scratch_mb", mb)
+                if stride == 1:
+                    out[mb] = ctx.render_image(p)[0]
+                else:
+                    local = torch.zeros((dev.num_local_tiles(w, h, stride), 64, 4), dtype=torch.float32, device="cuda")
+                    ctx.render_tiles(p, local.data_ptr(), None)
+                    torch.cuda.synchronize()
+                    out[mb] = local.cpu().numpy()
+            a, b = (np.ascontiguousarray(out[k]).view(np.uint32) for k in (budget, 0))
+            assert np.array_equal(a, b), (w, h, spp, chunks, first, stride)
+            if stride == 1:
+                assert (out[0][..., 3] == spp).all()
+    finally:
+        ctx.set_tunable("chunk_scratch_mb", budget)
+
+
 def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
     sb = srt.scenes.scene_spheres()
     ctx.upload_scene(sb)

@@ -547,9 +547,13 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
     spheres[3 * i + 1] = make_float4(s.center1[0], s.center1[1], s.center1[2], fb);
     spheres[3 * i + 2] = make_float4(s.time0, s.time1, 0.0f, 0.0f);
   }
+  // device index of a triangle: identity until the trees are built, then the order in which the host-built
+  // trees' leaves reference the triangles (below), so that a leaf's records and its neighbours' sit together
+  std::vector<int32_t> triDevIndex;
   auto devRef = [&](int32_t listRef) -> int32_t {  // ~primListIndex -> device prim ref
     const SrtPrimRef& p = d->prims[~listRef];
-    return ~((p.index << 1) | (p.type == SRT_PRIM_SPHERE ? 1 : 0));
+    if (p.type == SRT_PRIM_SPHERE) return ~((p.index << 1) | 1);
+    return ~((triDevIndex.empty() ? p.index : triDevIndex[p.index]) << 1);
   };
 
   // ---- world: build each bvhNode (consumes the global generator in scene order)
@@ -661,6 +665,63 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       texels.insert(texels.end(), src, src + n * t.bpp);
     }
     if (texels.size() > (size_t)0x7fffff00) return fail(ctx, "scene: more than 2 GiB of texels");
+  }
+  // ---- triangle records in tree order.  Device arrays were filled in the scene's own triangle order; a tree's
+  // leaves reference them at random (a mesh's index order has nothing to do with the median splits), and with
+  // millions of triangles every test is then a 48-byte gather from a cold place.  Renumber the triangles by
+  // their first appearance in the (pre-order) node arrays of the host-built trees: the two triangles of a leaf
+  // and the leaves of a subtree become neighbours in memory.  Triangles no host-built tree references keep
+  // their relative order behind them.  References are rewritten, nothing else changes (primitive ids reported
+  // by srtTraceRays go through triPrimId, which is permuted along).
+  if (d->numTriangles > 1 && !nodes.empty()) {
+    std::vector<int32_t> order(d->numTriangles, -1);
+    int32_t next = 0;
+    auto visit = [&](float bits) {
+      int32_t r;
+      memcpy(&r, &bits, 4);
+      if (r >= 0 || r == SRT_REF_DONE) return;
+      const int32_t pr = ~r;
+      if ((pr & 1) == 0 && (pr >> 1) < d->numTriangles && order[pr >> 1] < 0) order[pr >> 1] = next++;
+    };
+    for (size_t i = 0; i + 1 < nodes.size(); i += 2) {
+      visit(nodes[i].w);
+      visit(nodes[i + 1].w);
+    }
+    if (next > 0) {
+      for (int32_t i = 0; i < d->numTriangles; ++i)
+        if (order[i] < 0) order[i] = next++;
+      auto remap = [&](float& bits) {
+        int32_t r;
+        memcpy(&r, &bits, 4);
+        if (r >= 0 || r == SRT_REF_DONE) return;
+        const int32_t pr = ~r;
+        if (pr & 1) return;
+        r = ~(order[pr >> 1] << 1);
+        memcpy(&bits, &r, 4);
+      };
+      for (size_t i = 0; i + 1 < nodes.size(); i += 2) {
+        remap(nodes[i].w);
+        remap(nodes[i + 1].w);
+      }
+      for (int32_t& wr : world) {
+        float bits;
+        memcpy(&bits, &wr, 4);
+        remap(bits);
+        memcpy(&wr, &bits, 4);
+      }
+      std::vector<float4> tt(triTest.size()), ts(triShade.size());
+      std::vector<int32_t> tp(triPrimId.size());
+      for (int32_t i = 0; i < d->numTriangles; ++i) {
+        const int32_t j = order[i];
+        for (int k = 0; k < 3; ++k) tt[3 * (size_t)j + k] = triTest[3 * (size_t)i + k];
+        for (int k = 0; k < 4; ++k) ts[4 * (size_t)j + k] = triShade[4 * (size_t)i + k];
+        tp[j] = triPrimId[i];
+      }
+      triTest.swap(tt);
+      triShade.swap(ts);
+      triPrimId.swap(tp);
+      triDevIndex.swap(order);  // devRef of the device-built trees below
+    }
   }
   DevScene& s = ctx->scene;
   memset(&s, 0, sizeof s);
@@ -871,18 +932,6 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.sppBase = a.spp / a.sppChunks;
   a.sppRem = a.spp % a.sppChunks;
-  {
-    // the launch's invariant divisors (srtDiv, srtTileFromOrderFast)
-    const int B = a.tileBlock, hLast = a.tilesY % B, wLast = a.tilesX % B;
-    a.divUnitItems = srtMakeDivisor((uint32_t)a.unitTiles * a.sppChunks * SRT_TILE_PIXELS);
-    a.divChunks = srtMakeDivisor((uint32_t)a.sppChunks);
-    a.divRow = srtMakeDivisor((uint32_t)B * a.tilesX);
-    a.divBlockFull = srtMakeDivisor((uint32_t)B * B);
-    a.divBlockLast = srtMakeDivisor((uint32_t)B * (hLast ? hLast : B));
-    a.divB = srtMakeDivisor((uint32_t)B);
-    a.divWLast = srtMakeDivisor((uint32_t)(wLast ? wLast : B));
-  }
-  a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
   a.shadeMin = ctx->tun.shadeMin;
   a.primMin = ctx->tun.primMin;
   a.hitMin = ctx->tun.hitMin;

@@ -71,32 +71,6 @@ struct DevCamera {
   float lensRadius, time0, time1;
 };
 
-// Division of a 31-bit numerator by an invariant divisor as one multiply-high and one shift (Granlund /
-// Montgomery): for d >= 2 with 2^(l-1) < d <= 2^l, m = floor(2^(31+l) / d) + 1 fits 32 bits and
-// n / d = mulhi(n, m) >> (l - 1) for every 0 <= n < 2^31 (m * d - 2^(31+l) <= 2^l).  The work-item
-// decomposition of the render kernels divides by seven launch constants (unit size, chunk count, tile-order
-// block sizes); a hardware-less 32-bit division costs ~35 VALU instructions each.
-struct SrtDivisor {
-  uint32_t d, m, s;  // divisor, magic multiplier, shift (d == 1: m unused)
-};
-#if defined(__HIPCC__)
-__device__ __forceinline__ int srtDiv(int n, const SrtDivisor& k) {
-  return k.d == 1 ? n : (int)(__umulhi((uint32_t)n, k.m) >> k.s);
-}
-#endif
-inline SrtDivisor srtMakeDivisor(uint32_t d) {
-  SrtDivisor k{d, 0, 0};
-  if (d <= 1) {
-    k.d = 1;
-    return k;
-  }
-  uint32_t l = 0;
-  while ((1ull << l) < d) ++l;  // 2^(l-1) < d <= 2^l
-  k.m = (uint32_t)(((1ull << (31 + l)) / d) + 1ull);
-  k.s = l - 1;
-  return k;
-}
-
 struct SrtFixedAccum {  // 32 B per pixel of a rank's tile buffer: exact sum of the items' partial sums (commitFixed)
   long long r, g, b;    // units of 2^-36
   uint32_t flags;       // bit k: a NaN partial sum in channel k; bit 3+k: +inf; bit 6+k: -inf
@@ -117,8 +91,6 @@ struct RenderArgs {
   int32_t unitTiles, numUnits;  // queue q owns units q, q+numQueues, ... of unitTiles consecutive local tiles
   int32_t sppChunks;
   int32_t sppBase, sppRem;  // chunk c renders samples [c * sppBase + min(c, sppRem), ...): spp = sppChunks * sppBase + sppRem
-  SrtDivisor divUnitItems, divChunks;                       // work item index -> (unit, tile in unit, chunk)
-  SrtDivisor divRow, divBlockFull, divBlockLast, divB, divWLast;  // tile order position -> (tx, ty), see srtTileFromOrderFast
   int32_t numWork;  // numLocalTiles * sppChunks * 64 (one item = one pixel x one sample chunk)
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
@@ -172,26 +144,6 @@ SRT_HD inline void srtTileFromOrder(int i, int tilesX, int tilesY, int B, int& t
   tx = bx * B + ix;
   ty = by * B + iy;
 }
-#if defined(__HIPCC__)
-// srtTileFromOrder with the launch's precomputed divisors: divRow = B * tilesX, divBlockFull = B * B,
-// divBlockLast = B * (height of the last, lower block row), divB = B, divWLast = width of the last block column
-__device__ __forceinline__ void srtTileFromOrderFast(int i, int tilesX, int tilesY, int B, const SrtDivisor& divRow,
-                                                     const SrtDivisor& divBlockFull, const SrtDivisor& divBlockLast,
-                                                     const SrtDivisor& divB, const SrtDivisor& divWLast, int& tx, int& ty) {
-  const int by = srtDiv(i, divRow), r = i - by * (int)divRow.d;
-  const bool lastRow = (tilesY - by * B) < B;
-  const int bh = lastRow ? (tilesY - by * B) : B;
-  const int bx = lastRow ? srtDiv(r, divBlockLast) : srtDiv(r, divBlockFull), r2 = r - bx * B * bh;
-  const bool lastCol = (tilesX - bx * B) < B;
-  const int bw = lastCol ? (tilesX - bx * B) : B;
-  const int iy = lastCol ? srtDiv(r2, divWLast) : srtDiv(r2, divB), ixr = r2 - iy * bw;
-  const int rot = iy - (lastCol ? srtDiv(iy, divWLast) : srtDiv(iy, divB)) * bw;  // iy % bw
-  int ix = ixr - rot;
-  ix = ix < 0 ? ix + bw : ix;
-  tx = bx * B + ix;
-  ty = by * B + iy;
-}
-#endif
 SRT_HD inline int srtOrderFromTile(int tx, int ty, int tilesX, int tilesY, int B) {
   const int by = ty / B, iy = ty - by * B, bx = tx / B, ix = tx - bx * B;
   const int bh = (tilesY - by * B) < B ? (tilesY - by * B) : B;

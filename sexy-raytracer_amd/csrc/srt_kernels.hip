@@ -1180,14 +1180,17 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             s = sEnd = 0;
           } else {
             // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk
-            const int u = srtDiv(idx, a.divUnitItems), inUnit = idx - u * unitItems;
+            // plain divisions: replacing these seven by multiply-high forms with launch-constant magic numbers
+            // measured 3 % SLOWER on the headline frame (3297 against 3401 Msamples/s, same box,
+            // profiles/r02/bisect_divisions.txt) -- the item decomposition runs once per 78 samples and the shorter
+            // code changed the register allocation of the steps around it for the worse
+            const int u = idx / unitItems, inUnit = idx - u * unitItems;
             const int group = inUnit >> 6, ln = inUnit & 63;
-            const int tileInUnit = srtDiv(group, a.divChunks), chunk = group - tileInUnit * a.sppChunks;
+            const int tileInUnit = group / a.sppChunks, chunk = group - tileInUnit * a.sppChunks;
             const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
             const int tile = a.tileFirst + localTile * a.tileStride;
             int tx, ty;
-            srtTileFromOrderFast(tile < a.numTiles ? tile : 0, a.tilesX, a.tilesY, a.tileBlock, a.divRow, a.divBlockFull,
-                                 a.divBlockLast, a.divB, a.divWLast, tx, ty);
+            srtTileFromOrder(tile < a.numTiles ? tile : 0, a.tilesX, a.tilesY, a.tileBlock, tx, ty);
             px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
             py = ty * SRT_TILE_H + (ln >> 3);
             pixel = (uint32_t)(py * a.imageWidth + px);

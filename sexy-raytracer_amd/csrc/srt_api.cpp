@@ -932,6 +932,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.sppBase = a.spp / a.sppChunks;
   a.sppRem = a.spp % a.sppChunks;
+  a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
   a.shadeMin = ctx->tun.shadeMin;
   a.primMin = ctx->tun.primMin;
   a.hitMin = ctx->tun.hitMin;

@@ -317,7 +317,7 @@ const TunableName kTunables[] = {
     {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 32},
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
-    {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 1024},  // budget of the chunk-slot path, whole frame
+    {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -855,14 +855,20 @@ int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
   return (srtNumTiles(w, h) + stride - 1) / stride;
 }
 
-// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): min(64, spp).
-// Many items per pixel keep the tiles in flight few -- a queue's waves pull consecutive items, i.e. the chunks
-// of one tile, then of its neighbour -- and that coherence is worth more than the cost of small items.
-// Round 2, 720p headline at 5000 spp (Msamples/s): 1 chunk 500, 2: 1381, 4: 2274, 8: 2810, 16: 2983, 32: 3195,
-// 64: 3333, 157: 3335, 256: 3312, 1024: 3178 (profiles/r02/chunk_sweep.txt).  64 keeps the chunk slots of a
-// 720p frame under 1 GiB (srtRenderTiles: scratch path); low sample counts get one sample per item (64 spp on
-// the 240p spheres frame: 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks).
-int32_t srtDefaultSppChunks(int32_t spp) { return std::max(1, std::min(64, spp)); }
+// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about 32 samples per
+// item, at least 128 items per pixel when there are that many samples (down to one sample per item), at most 160.
+// It depends on the sample count alone, so that the chunk boundaries -- and with them the image, bit for bit --
+// are the same for every tile split and GPU count.  Many items per pixel keep the tiles in flight few (a queue's
+// waves pull consecutive items, i.e. the chunks of one tile, then of its neighbour) and that coherence is worth
+// more than the cost of small items; a small share of a frame needs it most.  Round 2, 720p headline at 5000 spp
+// (profiles/r02/chunk_policy.txt): whole frame 1 chunk 500, 4: 2274, 16: 2983, 32: 3195, 64: 3395, 157: 3393,
+// 256: 3362, 1024: 3178 Msamples/s; one of 8 ranks' share 219 / 186 / 184 ms with 64 / 157 / 256 chunks
+// (169 ms would be an eighth of the frame).  Low sample counts: 64 spp on the 240p spheres frame run at
+// 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks.
+int32_t srtDefaultSppChunks(int32_t spp) {
+  const int32_t bySize = (spp + 31) / 32, byCount = std::min(128, spp);
+  return std::max(1, std::min(160, std::max(bySize, byCount)));
+}
 
 static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
@@ -949,10 +955,10 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   bool scratchPath = false;
   if (a.sppChunks > 1) {
     // Chunk sums are added exactly (srt_kernels.hip "Chunk sums").  Scratch path (a float4 slot per item, summed by
-    // srt_sum_chunks_kernel) while the WHOLE frame's slots fit the budget -- decided on the frame, not on this
-    // rank's share, so that the choice is the same for every rank count -- else the atomic path (32 B per pixel).
-    const size_t frameSlots = (size_t)a.numTiles * SRT_TILE_PIXELS * a.sppChunks * sizeof(float4);
-    scratchPath = frameSlots <= (size_t)std::max(0, ctx->tun.chunkScratchMb) * 1024 * 1024;
+    // srt_sum_chunks_kernel) while this rank's slots fit the budget, else the atomic path (32 B per pixel, 0.4-1 %
+    // slower); the two give the same bits, so the choice may differ from rank to rank.
+    const size_t localSlots = tilePixels * a.sppChunks * sizeof(float4);
+    scratchPath = localSlots <= (size_t)std::max(0, ctx->tun.chunkScratchMb) * 1024 * 1024;
     const size_t need = scratchPath ? tilePixels * a.sppChunks * sizeof(float4) : tilePixels * sizeof(SrtFixedAccum);
     if (ctx->chunkScratch.bytes < need) {
       if (ctx->chunkScratch.p) HIP_OK(ctx, hipFree(ctx->chunkScratch.p));

@@ -710,10 +710,10 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 //     converts and adds the slots (one plain store per item in the render kernel, chunks x 16 B per pixel);
 //   * atomic path (commitFixed): items add their fixed-point partials with three 64-bit integer atomics into
 //     32 B per pixel; srt_finalize_kernel rounds.  Memory is O(pixels) for any chunk count, at the price of the
-//     memory-side atomics (scattered 8-byte atomics retire at ~20 G/s chip-wide: 1-2 % on the 720p headline,
-//     a third of the time of a 240p / 64-spp frame).
-// srtRenderTiles picks the scratch path while the whole frame's slots fit a memory budget, the atomic path
-// beyond; the image is the same bit for bit.
+//     memory-side atomics (scattered 8-byte atomics retire at ~20 G/s chip-wide: 0.4-1 % on the 720p headline
+//     with 64-256 chunks, a third of the time of a 240p frame with one-sample items).
+// srtRenderTiles picks the scratch path while the rank's slots fit a memory budget, the atomic path beyond; the
+// image is the same bit for bit.
 // A float of 2^-12 or more converts exactly (its ulp is >= 2^-36; smaller ones are truncated to 2^-36
 // absolute), so two chunk sums a, b >= 2^-12 give fl(a + b) bit for bit.  NaN / infinite partial sums (the
 // r = 0 ground BRDF produces NaN samples) poison the channel as they would a float sum.

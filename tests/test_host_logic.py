@@ -147,9 +147,9 @@ def test_no_gpu_is_an_error_not_a_fallback(dev):
 
 
 def test_default_chunk_plan(dev):
-    """srtDefaultSppChunks: min(64, spp) work items per pixel (srt_api.cpp: the measured knee of the chunk
-    sweep; 64 slots of a 720p frame stay under the 1 GiB budget of the chunk-slot path)."""
-    want = {1: 1, 2: 2, 16: 16, 64: 64, 100: 64, 128: 64, 333: 64, 1000: 64, 5000: 64, 8192: 64, 10 ** 6: 64}
+    """srtDefaultSppChunks: ~32 samples per item, at least 128 items per pixel when there are that many
+    samples, never more chunks than samples, at most 160 (srt_api.cpp); a function of the sample count alone."""
+    want = {1: 1, 2: 2, 16: 16, 64: 64, 100: 100, 128: 128, 333: 128, 1000: 128, 4096: 128, 5000: 157, 8192: 160, 10 ** 6: 160}
     for spp, chunks in want.items():
         assert dev.default_spp_chunks(spp) == chunks, spp
         assert 1 <= dev.default_spp_chunks(spp) <= spp

@@ -20,7 +20,7 @@
 #define SRT_REF_DONE ((int32_t)0x80000000)
 #define SRT_NODE_REF(index) ((int32_t)(index) << 5)
 #define SRT_NODE_INDEX(ref) ((int32_t)(ref) >> 5)
-#define SRT_MAX_NODES (1 << 26) /* byte offsets stay below 2^31 */
+#define SRT_MAX_NODES (1 << 25) /* byte offsets (index * 64 in the closest-hit records) stay below 2^31 */
 #define SRT_MAX_QUEUES 64
 
 struct DevMaterial {  // 48 B
@@ -50,6 +50,11 @@ struct DevScene {
   const float4* triShade;
   // 3 x float4 per sphere: (c0.xyz, radius) (c1.xyz, material | moving<<30) (t0, t1, -, -)   -- 16..48 B / test
   const float4* spheres;
+  // SRT_TRAVERSE_CLOSEST only: one 64-byte record per node holding BOTH children's boxes,
+  // (lmin.xyz, left) (lmax.xyz, right) (rmin.xyz, -) (rmax.xyz, -), node children as byte offsets into this array
+  // (index * 64); built from `nodes` on the device after upload (srt_lbvh.hip, srt_pair_nodes).  One 64-byte request
+  // per visit tests two boxes; the 32-byte records use half of every request they cause.
+  const float4* nodes2;
   // 1 byte per node: the axis its children are split on (left = lower side), 3 = unknown.  Read only by
   // SRT_TRAVERSE_CLOSEST, which visits the nearer child first; FAITHFUL keeps bvh.h's left-then-right.
   const uint8_t* nodeAxis;
@@ -95,6 +100,7 @@ struct RenderArgs {
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
   int32_t nodeBurst;          // max node visits per scheduling decision
+  int32_t primAgainMin;       // lanes at a primitive again after a primitive step for a second round in the same trip
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // sppChunks == 1: the caller's [localTile][64] buffer (the reference's float running sum, written
                     // directly); scratch path: chunk slots [chunk][localTile][64]

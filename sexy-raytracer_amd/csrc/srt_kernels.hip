@@ -36,6 +36,10 @@
 #ifndef SRT_NODE_UNROLL_CLOSEST
 #define SRT_NODE_UNROLL_CLOSEST 4  // same for the near-child-first variant (tunable separately)
 #endif
+#ifndef SRT_PRIM_ROUNDS
+#define SRT_PRIM_ROUNDS 2  // primitive tests per scheduling trip (2: the second object of a two-object leaf in the same trip;
+                           // headline frame 3392 / 3425 / 3414 Msamples/s with 1 / 2 / 3, profiles/r02/prim_rounds.txt)
+#endif
 #ifndef SRT_RENDER_WAVES_PER_SIMD
 #define SRT_RENDER_WAVES_PER_SIMD 5
 #endif
@@ -272,6 +276,19 @@ __device__ __forceinline__ bool boxHitApprox(float4 n0, float4 n1, V3 r1, V3 m, 
   const float tol = __builtin_fmaf(0x1p-21f, fabsf(tMax) + fabsf(tMin), tolAbs);
   undecided = !(fabsf(diff) > tol);  // also when a NaN got in, and always when tolAbs = +inf
   return diff > tol;
+}
+// Closest-hit traversal: the same one-FMA intervals used CONSERVATIVELY -- a box is entered unless it is certainly
+// missed (tMaxA - tMinA < -tol), so no exact fallback is needed: a box entered needlessly costs time, never a hit.
+// Returns the approximate entry distance for near-first ordering.
+__device__ __forceinline__ bool boxMaybeHit(float4 lo, float4 hi, V3 r1, V3 m, float tolAbs, float tMin, float tMax, float& tEnter) {
+  const float ax = __builtin_fmaf(lo.x, r1.x, m.x), bx = __builtin_fmaf(hi.x, r1.x, m.x);
+  const float ay = __builtin_fmaf(lo.y, r1.y, m.y), by = __builtin_fmaf(hi.y, r1.y, m.y);
+  const float az = __builtin_fmaf(lo.z, r1.z, m.z), bz = __builtin_fmaf(hi.z, r1.z, m.z);
+  const float t0 = hwMax(hwMax3(hwMin(ax, bx), hwMin(ay, by), hwMin(az, bz)), tMin);
+  const float t1 = hwMin(hwMin3(hwMax(ax, bx), hwMax(ay, by), hwMax(az, bz)), tMax);
+  const float tol = __builtin_fmaf(0x1p-21f, fabsf(t1) + fabsf(t0), tolAbs);
+  tEnter = t0;
+  return !(t1 - t0 < -tol);  // NaN or tolAbs = +inf (uncertified ray): enter
 }
 // per ray: m = fl(-o * r) and the absolute part of the certificate's tolerance
 __device__ __forceinline__ void slabSetup(const V3& o, const V3& r1, bool certified, V3& m, float& tolAbs) {
@@ -789,6 +806,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const V3 background = ld3(a.background);
   const DevScene& sc = a.scene;
   const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
+  const __amdgpu_buffer_rsrc_t rsNodes2 = makeRsrc(sc.nodes2, CLOSEST ? sc.numNodes * 64 : 0);
   const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
   const __amdgpu_buffer_rsrc_t rsTexels = makeRsrc(sc.texels, sc.texelBytes);
@@ -875,6 +893,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     sptr -= SRT_BLOCK;
     if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
       next = sc.world[w];
+      if (CLOSEST && next >= 0) next <<= 1;
       sptr = stackBase;
     }
     cur = next;
@@ -899,6 +918,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     sptr = stackBase;
     w = 0;
     cur = sc.world[0];
+    if (CLOSEST && cur >= 0) cur <<= 1;  // node references of the closest-hit traversal address the 64-byte records
     pend = 1;  // a miss unless a hit-shading step says otherwise
   };
 
@@ -927,32 +947,44 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     int nNodes = nN;
     if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
-      if (atPrim()) {
-        const int pending = *sptr;  // for popNext, read while the primitive's record is on its way
-        int pr = ~cur;
-        float t;
-        bool ok;
-        if (pr & 1) {
-          if (COUNT) cSph++;
-          const int off = (pr >> 1) * 48;
-          float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
-          V3 center = mk(s0.x, s0.y, s0.z);
-          if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
-            float4 s2 = bufLoad4(rsSpheres, off + 32);
-            center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
+      // A two-object leaf leaves its second primitive pending right behind the first (bvh.h:70-78): when enough
+      // lanes are at a primitive again after the first test, test those in the same trip.
+      for (int round = 0; round < SRT_PRIM_ROUNDS; ++round) {
+        if (round > 0) {
+          const int again = __popcll(__ballot(atPrim()));
+          if (again < a.primAgainMin) break;
+          if (COUNT) {
+            pSteps[M_PRIM]++;
+            pLanes[M_PRIM] += again;
           }
-          ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
-        } else {
-          if (COUNT) cTri++;
-          const int off = (pr >> 1) * 48;
-          ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray,
-                                a.tMin, closest, t);
         }
-        if (ok) {
-          closest = t;
-          hitRef = cur;
+        if (atPrim()) {
+          const int pending = *sptr;  // for popNext, read while the primitive's record is on its way
+          int pr = ~cur;
+          float t;
+          bool ok;
+          if (pr & 1) {
+            if (COUNT) cSph++;
+            const int off = (pr >> 1) * 48;
+            float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
+            V3 center = mk(s0.x, s0.y, s0.z);
+            if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
+              float4 s2 = bufLoad4(rsSpheres, off + 32);
+              center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
+            }
+            ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
+          } else {
+            if (COUNT) cTri++;
+            const int off = (pr >> 1) * 48;
+            ok = triHitV<CLOSEST>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray,
+                                  a.tMin, closest, t);
+          }
+          if (ok) {
+            closest = t;
+            hitRef = cur;
+          }
+          popNext(pending);
         }
-        popNext(pending);
       }
       // most of these lanes are back at nodes now: go on with a node burst in the same trip instead of
       // paying for another scheduling decision (scalar work) first
@@ -980,6 +1012,41 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
           if (COUNT) {
             pSteps[M_NODE]++;
             pLanes[M_NODE] += __popcll(__ballot(atNode()));
+          }
+          if (CLOSEST) {
+            // closest-hit traversal over the 64-byte records (both children's boxes per node, DevScene::nodes2):
+            // one 64-byte request per visit, two boxes tested, the nearer child entered first, no exact fallback
+            if (atNode()) {
+              const float4 l0 = bufLoad4(rsNodes2, cur), l1 = bufLoad4(rsNodes2, cur + 16), r0 = bufLoad4(rsNodes2, cur + 32),
+                           r1 = bufLoad4(rsNodes2, cur + 48);
+              const int top = *sptr;
+              if (COUNT) cNodes += 2;  // two boxes, 2 x 32 bytes, per record
+              const int left = __float_as_int(l0.w), right = __float_as_int(l1.w);
+              float tl, tr;
+              bool hl = boxMaybeHit(l0, l1, rcpD, negOR, slabTol, a.tMin, closest, tl);
+              bool hr = boxMaybeHit(r0, r1, rcpD, negOR, slabTol, a.tMin, closest, tr);
+              if (slabTol == SRT_INF) {
+                // a ray outside the certified operand ranges (a zero or tiny direction component ...): "cannot rule
+                // the box out" would let it walk the whole tree -- on a 10 M-triangle scene a handful of such rays
+                // then take longer than all the others together -- so these take the reference's own test
+                hl = boxHit(l0, l1, ray, a.tMin, closest);
+                hr = boxHit(r0, r1, ray, a.tMin, closest);
+              }
+              hr = hr && right != left;
+              if (COUNT) cBox += (hl ? 1 : 0) + (hr ? 1 : 0);
+              const bool both = hl && hr, leftFirst = !hr || (hl && !(tr < tl));
+              const int nearRef = leftFirst ? left : right, farRef = leftFirst ? right : left;
+              sptr[SRT_BLOCK] = farRef;  // the slot above the top is free; live only if sptr is bumped
+              int move = (hl || hr) ? (both ? 1 : 0) : -1;
+              asm("" : "+v"(move));
+              sptr += move * SRT_BLOCK;
+              cur = (hl || hr) ? nearRef : top;
+              if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {
+                cur = sc.world[w] >= 0 ? sc.world[w] << 1 : sc.world[w];
+                sptr = stackBase;
+              }
+            }
+            return;
           }
           if (atNode()) {
             float4 n0 = bufLoad4(rsNodes, cur), n1 = bufLoad4(rsNodes, cur + 16);  // node references are byte offsets

@@ -385,6 +385,48 @@ __global__ void plocMerge(const PlocCluster* c, const int* nn, const unsigned lo
 
 }  // namespace
 
+// The closest-hit traversal's node records: both children's boxes in one 64-byte record (DevScene::nodes2).
+// A node child's box is that node's own box; a primitive child's box is computed by the reference's
+// boundingBox rules over [time0, time1] (the widest range of the scene's items: a larger box is still correct,
+// the traversal only needs boxes that contain their primitives).
+namespace {
+__global__ void pairNodes(DevScene sc, float time0, float time1, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc.numNodes) return;
+  const float4 n0 = sc.nodes[2 * (size_t)i], n1 = sc.nodes[2 * (size_t)i + 1];
+  const int refs[2] = {__float_as_int(n0.w), __float_as_int(n1.w)};
+  float4 rec[4];
+  for (int c = 0; c < 2; ++c) {
+    float mn[3], mx[3];
+    int ref = refs[c];
+    if (ref >= 0) {
+      const int j = SRT_NODE_INDEX(ref);
+      const float4 c0 = sc.nodes[2 * (size_t)j], c1 = sc.nodes[2 * (size_t)j + 1];
+      mn[0] = c0.x; mn[1] = c0.y; mn[2] = c0.z;
+      mx[0] = c1.x; mx[1] = c1.y; mx[2] = c1.z;
+      ref = j << 6;  // byte offset of the child's 64-byte record
+    } else if (ref == SRT_REF_DONE || ref == 0) {
+      mn[0] = mn[1] = mn[2] = 1.0f;  // unused slot (padding record): an empty box
+      mx[0] = mx[1] = mx[2] = -1.0f;
+    } else {
+      primBox(sc, ref, time0, time1, mn, mx);
+    }
+    rec[2 * c + 0] = make_float4(mn[0], mn[1], mn[2], c == 0 ? __int_as_float(ref) : 0.0f);
+    rec[2 * c + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    if (c == 1) rec[1].w = __int_as_float(ref);
+  }
+  for (int k = 0; k < 4; ++k) out[4 * (size_t)i + k] = rec[k];
+}
+}  // namespace
+
+extern "C" int srt_pair_nodes(const DevScene* sc, float time0, float time1, float4* out) {
+  if (sc->numNodes <= 0) return 0;
+  hipLaunchKernelGGL(pairNodes, dim3((sc->numNodes + 255) / 256), dim3(256), 0, nullptr, *sc, time0, time1, out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return (int)e;
+}
+
 // Same contract as srt_lbvh_build.  radius: clusters examined on either side (1..128).
 extern "C" int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                               uint8_t* outAxis, int base, int radius, int* depthOut) {

@@ -3,7 +3,7 @@
  *
  * NOT part of the drop-in boundary (include/srt_hip.h): nothing here is needed to render.  These entry
  * points let the parity tests reach device functions of the hot path in isolation (the kernel's own
- * shading function, its slab-test division, the render kernel's own traversal per ray) and let the
+ * shading function, the render kernel's own traversal per ray) and let the
  * measurement tools vary the work distribution.  HOST pointers throughout.
  */
 #ifndef SRT_HIP_TEST_H
@@ -20,10 +20,6 @@ extern "C" {
  * keyed (seed, pixel=i, sample=0).  out13 per entry: attenuation[3], scattered dir[3],
  * scattered origin[3], scatter's bool, emitted[3].  HOST pointers. */
 int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
-
-/* Test hook: the slab test's per-ray-reciprocal division (srt_kernels.hip fastDiv) next to the
- * plain IEEE division on count operand pairs.  HOST pointers. */
-int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow);
 
 /* Per-ray view into the RENDER kernel's own traversal (not srtTraceRays' kernel): renders sample
  * p->sampleFirst of every pixel with the counting variant of srt_render_kernel and records, per pixel, the

@@ -33,7 +33,6 @@ int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0,
 int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                    uint8_t* outAxis, int base, int radius, int* depthOut);
 int srt_pair_nodes(const DevScene* sc, float time0, float time1, float4* out);
-int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
 }
@@ -1121,28 +1120,6 @@ int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int3
   if (dHits) (void)hipFree(dHits);
   if (dOut) (void)hipFree(dOut);
   return rc;
-}
-
-// test entry: the slab test's reciprocal-based division against the plain IEEE division
-int srtDivTest(SrtContext* ctx, const float* n, const float* d, int32_t count, float* outFast, float* outSlow) {
-  if (!ctx || !n || !d || !outFast || !outSlow || count < 1) return 1;
-  HIP_OK(ctx, hipSetDevice(ctx->device));
-  float* buf = nullptr;
-  size_t bytes = (size_t)count * sizeof(float);
-  HIP_OK(ctx, hipMalloc((void**)&buf, 4 * bytes));
-  int rc = 1;
-  do {
-    if (hipMemcpy(buf, n, bytes, hipMemcpyHostToDevice) != hipSuccess) break;
-    if (hipMemcpy(buf + count, d, bytes, hipMemcpyHostToDevice) != hipSuccess) break;
-    if (srt_launch_divtest(buf, buf + count, buf + 2 * (size_t)count, buf + 3 * (size_t)count, count, nullptr)) break;
-    if (hipDeviceSynchronize() != hipSuccess) break;
-    if (hipMemcpy(outFast, buf + 2 * (size_t)count, bytes, hipMemcpyDeviceToHost) != hipSuccess) break;
-    if (hipMemcpy(outSlow, buf + 3 * (size_t)count, bytes, hipMemcpyDeviceToHost) != hipSuccess) break;
-    rc = 0;
-  } while (0);
-  (void)hipFree(buf);
-  if (rc) return fail(ctx, "srtDivTest failed");
-  return 0;
 }
 
 int srtLastKernelMs(SrtContext* ctx, float* ms) {

@@ -9,8 +9,9 @@
 // Execution model (CDNA4), details at srt_render_kernel:
 //   * every lane is a persistent worker: it pulls a work item (one pixel x one chunk of its
 //     samples; 64 consecutive items = one 8x8 tile) from an atomic counter, runs the chunk's samples in
-//     index order and adds them in that order (main.cpp:204-218), writes one float4 partial sum and pulls
-//     the next item.  Accumulators are reproducible bit for bit and independent of tiling / GPU count.
+//     index order and adds them in that order (main.cpp:204-218), hands in one float partial sum and pulls
+//     the next item; the partial sums of a pixel are added exactly (64-bit fixed point, "Chunk sums" below).
+//     Accumulators are reproducible bit for bit and independent of scheduling, tiling and GPU count.
 //   * a wave-level scheduler runs ONE kind of step per trip -- BVH node visits, primitive tests, hit
 //     shading or path restarts -- for the lanes that are in that state, picked from ballot counts, so the
 //     64 lanes stay busy although their paths are at different depths of different subtrees.
@@ -21,7 +22,10 @@
 //     right children on a per-lane LDS stack laid out [slot][thread] (bank = thread: conflict-free).
 //   * RNG: PCG32 keyed by (seed, pixel, sample) per lane.
 //   * all arithmetic keeps the reference's operation order; built with -ffp-contract=off; divisions and
-//     sqrt are IEEE (hipcc default); the slab test's divisions go through a certified exact shortcut.
+//     sqrt are IEEE (hipcc default); the slab test is decided from one FMA per plane under an error
+//     certificate, with the IEEE divisions for the visits it cannot decide (boxHitApprox).
+//   * SRT_TRAVERSE_CLOSEST (not the parity path) walks 64-byte records that hold both children's boxes,
+//     nearer child first.
 // No MFMA: there is no dense contraction on this path.
 
 #include <hip/hip_runtime.h>
@@ -141,29 +145,15 @@ __device__ __forceinline__ float4 bufLoad4(__amdgpu_buffer_rsrc_t r, int byteOff
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// ------------------------------------------------------------------ exact division with a per-ray reciprocal
-// hipcc lowers the IEEE f32 division n / d to
-//   ds = div_scale(d), ns = div_scale(n); r0 = rcp(ds); r1 = fma(fma(-ds, r0, 1), r0, r0);
-//   q0 = ns*r1; q1 = fma(fma(-ds, q0, ns), r1, q0); q = div_fmas(fma(-ds, q1, ns), r1, q1); div_fixup(q, d, n)
-// When neither operand needs scaling (no zero/denormal/huge operand, quotient far from the
-// denormal and overflow ranges) div_scale, div_fmas' post-scale and div_fixup are the identity
-// and the quotient is the last fma.  r1 depends on d only, so the slab test (six divisions by the
-// three ray-direction components per BVH node, aabb.h:14-17) can reuse one r1 per axis per ray and
-// spend 5 VALU instructions per division instead of 11, with bit-identical quotients.  `rayFast`
-// certifies the operand ranges per ray (and the scene's box coordinates at upload); anything
-// outside them takes the plain `/`.  The only visible difference is the sign of a zero quotient,
-// which no comparison in the slab test can observe.
-__device__ __forceinline__ float refinedRcp(float d) {
+// ------------------------------------------------------------------ per-ray reciprocals and their operand ranges
+// The slab test (six divisions by the three ray-direction components per BVH node, aabb.h:14-17) is decided from
+// one FMA per plane with a refined reciprocal per axis per ray (boxHitApprox below).  The error bound of that
+// decision assumes normal operands: fastDivOperandOk certifies the ranges per ray (and the scene's box
+// coordinates at upload); a ray outside them takes the IEEE divisions on every visit.
+__device__ __forceinline__ float refinedRcp(float d) {  // within 1.5 ulp of 1/d: v_rcp_f32 + one Newton step
   float r0 = __builtin_amdgcn_rcpf(d);
   float e0 = __builtin_fmaf(-d, r0, 1.0f);
   return __builtin_fmaf(e0, r0, r0);
-}
-__device__ __forceinline__ float fastDiv(float n, float d, float r1) {
-  float q0 = n * r1;
-  float e1 = __builtin_fmaf(-d, q0, n);
-  float q1 = __builtin_fmaf(e1, r1, q0);
-  float e2 = __builtin_fmaf(-d, q1, n);
-  return __builtin_fmaf(e2, r1, q1);
 }
 // direction components in [2^-20, 2^20]; origin components 0 or in [2^-77, 2^30]
 __device__ __forceinline__ bool fastDivOperandOk(float o, float d) {
@@ -197,24 +187,6 @@ __device__ __forceinline__ bool boxHit(float4 n0, float4 n1, const Ray& r, float
   tMax = fminf(fmaxf(a, b), tMax);
   a = (n0.z - r.o.z) / r.d.z;
   b = (n1.z - r.o.z) / r.d.z;
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
-  return !(tMax <= tMin);
-}
-
-// the same slab test with the per-ray reciprocals (see fastDiv): bit-identical decisions
-__device__ __forceinline__ bool boxHitFast(float4 n0, float4 n1, const Ray& r, V3 r1, float tMin, float tMax) {
-  float a, b;
-  a = fastDiv(n0.x - r.o.x, r.d.x, r1.x);
-  b = fastDiv(n1.x - r.o.x, r.d.x, r1.x);
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
-  a = fastDiv(n0.y - r.o.y, r.d.y, r1.y);
-  b = fastDiv(n1.y - r.o.y, r.d.y, r1.y);
-  tMin = fmaxf(fminf(a, b), tMin);
-  tMax = fminf(fmaxf(a, b), tMax);
-  a = fastDiv(n0.z - r.o.z, r.d.z, r1.z);
-  b = fastDiv(n1.z - r.o.z, r.d.z, r1.z);
   tMin = fmaxf(fminf(a, b), tMin);
   tMax = fminf(fmaxf(a, b), tMax);
   return !(tMax <= tMin);
@@ -1452,22 +1424,8 @@ __global__ void srt_scatter_kernel(const ScatterArgs a) {
   o[10] = em.x; o[11] = em.y; o[12] = em.z;
 }
 
-// fastDiv vs the compiler's IEEE division on arbitrary operand arrays (srtDivTest)
-__global__ void srt_divtest_kernel(const float* n, const float* d, float* fast, float* slow, int count) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float dn = d[i], nn = n[i];
-  fast[i] = fastDiv(nn, dn, refinedRcp(dn));
-  slow[i] = nn / dn;
-}
-
 // =================================================================== launch wrappers (host)
 extern "C" {
-
-int srt_launch_divtest(const float* n, const float* d, float* fast, float* slow, int count, hipStream_t stream) {
-  hipLaunchKernelGGL(srt_divtest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, n, d, fast, slow, count);
-  return (int)hipGetLastError();
-}
 
 namespace {
 typedef void (*RenderKernel)(const RenderArgs);

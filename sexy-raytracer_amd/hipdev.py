@@ -26,7 +26,7 @@ EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostR
            "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtDivTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtRenderAov"]
+TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtRenderAov"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -58,7 +58,6 @@ lib.srtGatherTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _v
 lib.srtRenderImageRanks.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtCommDestroy.argtypes = [_vp]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
-lib.srtDivTest.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtGetShadeProfile.argtypes = [_vp, _vp]
@@ -236,22 +235,6 @@ class Context:
         out = np.zeros((len(rays), 13), np.float32)
         self._check(lib.srtScatterTest(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), seed, out.ctypes.data))
         return out
-
-    def div_test(self, n, d):
-        n = np.ascontiguousarray(n, np.float32)
-        d = np.ascontiguousarray(d, np.float32)
-        fast, slow = np.zeros_like(n), np.zeros_like(n)
-        self._check(lib.srtDivTest(self.h, n.ctypes.data, d.ctypes.data, len(n), fast.ctypes.data, slow.ctypes.data))
-        return fast, slow
-
-    def set_tunable(self, name, value):
-        """Diagnostic knobs of the work distribution / wave scheduler (include/srt_hip_test.h)."""
-        self._check(lib.srtSetTunable(self.h, name.encode(), int(value)))
-
-    def get_tunable(self, name):
-        v = C.c_int32(0)
-        self._check(lib.srtGetTunable(self.h, name.encode(), C.byref(v)))
-        return v.value
 
     def render_aov(self, params, depth=0):
         """The render kernel's own traversal of the ray at bounce `depth` of every pixel's first sample

@@ -286,36 +286,6 @@ def test_error_behaviour(dev, abi, srt, camera):
     c.close()
 
 
-def test_fast_division_is_the_ieee_division(ctx):
-    """The slab test divides by the ray direction through a per-ray refined reciprocal (fastDiv,
-    srt_kernels.hip).  Inside its certified operand ranges (|d| in [2^-20, 2^20], numerator 0 or
-    |n| in [2^-100, 2^31]) it must return the bits of the plain IEEE division, which in turn must be
-    the correctly rounded quotient (checked against numpy float64 -> float32)."""
-    rng = np.random.default_rng(17)
-    m = 4_000_000
-    d = (np.exp2(rng.uniform(-20, 20, m)) * rng.choice([-1.0, 1.0], m)).astype(np.float32)
-    n = (np.exp2(rng.uniform(-100, 31, m)) * rng.choice([-1.0, 1.0], m)).astype(np.float32)
-    # edge magnitudes, exact zeros, powers of two, near-tie quotients
-    n[:1000] = 0.0
-    n[1000:2000] = -0.0
-    d[2000:3000] = np.float32(2.0) ** rng.integers(-20, 21, 1000)
-    n[3000:4000] = (d[3000:4000].astype(np.float64) * (1.0 + rng.integers(1, 2 ** 23, 1000) * 2.0 ** -23)).astype(np.float32)
-    d[4000:4100], d[4100:4200] = np.float32(2.0 ** -20), np.float32(2.0 ** 20)
-    n[4200:4300], n[4300:4400] = np.float32(2.0 ** -100), np.float32(2.0 ** 31)
-    # realistic slab operands: (box - origin) / direction for coordinates of a few units
-    k = 1_000_000
-    n[-k:] = (rng.uniform(-10, 10, k).astype(np.float32) - rng.uniform(-10, 10, k).astype(np.float32))
-    d[-k:] = rng.normal(size=k).astype(np.float32)
-    ok = (np.abs(d) >= 2.0 ** -20) & (np.abs(d) <= 2.0 ** 20)
-    n, d = n[ok], d[ok]
-    fast, slow = ctx.div_test(n, d)
-    nz = slow != 0
-    assert np.array_equal(fast[nz].view(np.uint32), slow[nz].view(np.uint32))
-    assert (fast[~nz] == 0).all()  # only the sign of a zero quotient may differ
-    want = (n.astype(np.float64) / d.astype(np.float64)).astype(np.float32)
-    assert np.array_equal(slow.view(np.uint32), want.view(np.uint32))
-
-
 def test_progressive_passes_checkpoint_and_resume(tmp_path, ctx, oracle, abi, srt, camera):
     """Two passes of 8 samples (with a checkpoint written and resumed in between) add up bit for bit
     to one 16-sample render whose per-pixel sum is taken as two 8-sample chunks -- and each pass is the

@@ -407,13 +407,24 @@ def main():
     kernel_ms = []
     native_gather = world > 1 and backend == "nccl"
     gathered_buf = None
+    native_note = ""
     if native_gather:
         # the C-ABI's own communicator: rank 0 makes the id, torch.distributed (already up for the barrier
         # and the timing reduction) only carries its 128 bytes to the other ranks
         box = [dev.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(box[0], world, rank)
-        if rank == 0:
+        ok = 1
+        try:
+            ctx.comm_init(box[0], world, rank)
+        except Exception as e:  # every rank must take the same path: agree below
+            ok, native_note = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native_gather = False  # fall back to torch.distributed's gather (same bytes, same order) and say so
+            native_note = native_note or "srtCommInit failed on another rank"
+            sys.stderr.write("bench.py rank %d: native RCCL communicator unavailable (%s); using dist.gather\n" % (rank, native_note))
+        elif rank == 0:
             gathered_buf = torch.empty((world, nloc, 64, 4), dtype=torch.float32, device="cuda")
 
     def step(record):
@@ -488,7 +499,8 @@ def main():
                        "tree": builder, "traversal": "faithful (bvh.h order)" if traversal == "faithful" else "closest hit (not the parity path)",
                        "scene_build_upload_s": round(t_build, 2),
                        "parallelism": "tiles8x8 interleaved over %d rank(s), 1 gather (%s)" % (
-                           world, "srtGatherTiles: ncclGather" if native_gather else ("none" if world == 1 else "torch.distributed " + backend))},
+                           world, "srtGatherTiles: ncclGather" if native_gather else ("none" if world == 1 else "torch.distributed " + backend
+                                                                                     + (" (native communicator unavailable)" if native_note else "")))},
             "device": info,
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),

@@ -228,6 +228,7 @@ struct Tunables {
   int plocRadius, fastDiv;
   int chunkScratchMb;
   int primAgainMin;
+  int keepShift;
 };
 
 struct SrtContext {
@@ -319,6 +320,7 @@ const TunableName kTunables[] = {
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
+    {"keep_shift", "SRT_KEEP_SHIFT", &Tunables::keepShift, 2},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
 };
 
@@ -967,6 +969,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.fuseMin = ctx->tun.fuseMin;
   a.nodeBurst = std::max(1, ctx->tun.nodeBurst);
   a.primAgainMin = std::max(1, ctx->tun.primAgainMin);
+  a.keepShift = std::min(5, std::max(1, ctx->tun.keepShift));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   a.aov = p->countStats ? ctx->dAov : nullptr;

@@ -236,6 +236,15 @@ class Context:
         self._check(lib.srtScatterTest(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), seed, out.ctypes.data))
         return out
 
+    def set_tunable(self, name, value):
+        """Diagnostic knobs of the work distribution / wave scheduler (include/srt_hip_test.h)."""
+        self._check(lib.srtSetTunable(self.h, name.encode(), int(value)))
+
+    def get_tunable(self, name):
+        v = C.c_int32(0)
+        self._check(lib.srtGetTunable(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def render_aov(self, params, depth=0):
         """The render kernel's own traversal of the ray at bounce `depth` of every pixel's first sample
         (include/srt_hip_test.h): returns an AOV_DTYPE array (H, W)."""

@@ -164,3 +164,17 @@ def test_sphere_field_scene_is_deterministic(srt, oracle, dev):
     nodes, depth = dev.build_bvh_host(a)
     onodes, odepth = oracle.OracleScene(a).bvh(0)
     assert np.array_equal(nodes, onodes) and depth >= odepth
+
+
+def test_python_binding_covers_every_entry_point(dev):
+    """Every C entry point of both headers has ctypes argument types declared, and the Context wrapper still
+    carries the methods the GPU tests and tools call (a refactoring slip here only shows on the GPU box)."""
+    for name in dev.EXPORTS + dev.TEST_EXPORTS:
+        fn = getattr(dev.lib, name)
+        if name not in ("srtHostRandomFloat", "srtHostRandomReset"):
+            assert fn.argtypes is not None, name
+    for method in ("upload_scene", "set_camera", "bvh", "bvh_depth", "render_image", "render_tiles", "resolve_tiles",
+                   "comm_init", "gather_tiles", "render_image_ranks", "comm_destroy", "trace", "scatter_test",
+                   "set_tunable", "get_tunable", "render_aov", "shade_profile", "last_kernel_ms", "stats",
+                   "device_info", "fingerprint", "close"):
+        assert callable(getattr(dev.Context, method, None)), method

@@ -228,7 +228,7 @@ struct Tunables {
   int plocRadius, fastDiv;
   int chunkScratchMb;
   int primAgainMin;
-  int keepShift;
+  int keepEighths;
 };
 
 struct SrtContext {
@@ -312,15 +312,15 @@ const TunableName kTunables[] = {
     {"tile_block", nullptr, &Tunables::tileBlock, SRT_TILE_BLOCK},  // no environment override: ranks must agree (tiles.py)
     {"unit_tiles", "SRT_UNIT_TILES", &Tunables::unitTiles, -1},
     {"queues", "SRT_QUEUES", &Tunables::queues, -1},
-    {"shade_min", "SRT_SHADE_MIN", &Tunables::shadeMin, 16},
+    {"shade_min", "SRT_SHADE_MIN", &Tunables::shadeMin, 24},
     {"prim_min", "SRT_PRIM_MIN", &Tunables::primMin, 12},
     {"hit_min", "SRT_HIT_MIN", &Tunables::hitMin, 24},
     {"fuse_min", "SRT_FUSE_MIN", &Tunables::fuseMin, 32},
-    {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 32},
+    {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 64},
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
-    {"keep_shift", "SRT_KEEP_SHIFT", &Tunables::keepShift, 2},
+    {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, 4},  // round-2 sweep: 6 -> 4 is +3.5 % (profiles/r02/scheduler_sweep.txt)
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
 };
 
@@ -969,7 +969,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.fuseMin = ctx->tun.fuseMin;
   a.nodeBurst = std::max(1, ctx->tun.nodeBurst);
   a.primAgainMin = std::max(1, ctx->tun.primAgainMin);
-  a.keepShift = std::min(5, std::max(1, ctx->tun.keepShift));
+  a.keepEighths = std::min(8, std::max(0, ctx->tun.keepEighths));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   a.aov = p->countStats ? ctx->dAov : nullptr;

@@ -100,7 +100,7 @@ struct RenderArgs {
   int32_t shadeMin, primMin, hitMin;  // wave scheduler thresholds (lanes waiting before that step kind runs)
   int32_t fuseMin;            // lanes at nodes after a primitive step for a node burst to follow in the same trip
   int32_t nodeBurst;          // max node visits per scheduling decision
-  int32_t keepShift;          // a node burst goes on while nNodes - (nNodes >> keepShift) lanes are still at nodes
+  int32_t keepEighths;        // a node burst goes on while nNodes * keepEighths / 8 of its lanes are still at nodes
   int32_t primAgainMin;       // lanes at a primitive again after a primitive step for a second round in the same trip
   int32_t* queue;   // persistent-wave work counters, 16 ints apart (zeroed before launch)
   float4* out;      // sppChunks == 1: the caller's [localTile][64] buffer (the reference's float running sum, written

@@ -975,7 +975,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     if (pick == M_NODE) {
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105
       // several visits per scheduling decision while most of the node lanes are still at nodes
-      const int keep = nNodes - (nNodes >> a.keepShift);  // default: three quarters of the lanes that started the burst
+      const int keep = (nNodes * a.keepEighths) >> 3;  // the burst goes on while this many lanes are still at nodes
       int budget = a.nodeBurst;
       // SRT_NODE_UNROLL visits per loop trip: the "enough lanes left at nodes?" test is scalar work, and the scalar unit is
       // shared by the CU's four SIMDs

@@ -30,12 +30,12 @@ def main():
             "hit": [int(x) for x in os.environ.get("SWEEP_HIT", "24").split(",")],
             "fuse": [int(x) for x in os.environ.get("SWEEP_FUSE", "32").split(",")],
             "again": [int(x) for x in os.environ.get("SWEEP_AGAIN", "4").split(",")],
-            "keep": [int(x) for x in os.environ.get("SWEEP_KEEP", "2").split(",")]}
+            "keep": [int(x) for x in os.environ.get("SWEEP_KEEP", "6").split(",")]}
     for c, sm, pm, nb, hm, fu, ag, kp in itertools.product(grid["chunks"], grid["shade"], grid["prim"], grid["burst"], grid["hit"], grid["fuse"],
                                                            grid["again"], grid["keep"]):
-        for k, v in (("shade_min", sm), ("prim_min", pm), ("node_burst", nb), ("hit_min", hm), ("fuse_min", fu), ("prim_again_min", ag), ("keep_shift", kp)):
+        for k, v in (("shade_min", sm), ("prim_min", pm), ("node_burst", nb), ("hit_min", hm), ("fuse_min", fu), ("prim_again_min", ag), ("keep_eighths", kp)):
             ctx.set_tunable(k, v)
-        print("chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d fuseMin %2d againMin %2d keepShift %d : %8.1f Msamples/s" % (
+        print("chunks %3d shadeMin %2d primMin %2d burst %2d hitMin %2d fuseMin %2d againMin %2d keepEighths %d : %8.1f Msamples/s" % (
             c, sm, pm, nb, hm, fu, ag, kp, run(c)), flush=True)
 
 main()

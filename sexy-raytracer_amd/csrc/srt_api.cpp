@@ -312,15 +312,15 @@ const TunableName kTunables[] = {
     {"tile_block", nullptr, &Tunables::tileBlock, SRT_TILE_BLOCK},  // no environment override: ranks must agree (tiles.py)
     {"unit_tiles", "SRT_UNIT_TILES", &Tunables::unitTiles, -1},
     {"queues", "SRT_QUEUES", &Tunables::queues, -1},
-    {"shade_min", "SRT_SHADE_MIN", &Tunables::shadeMin, 24},
+    {"shade_min", "SRT_SHADE_MIN", &Tunables::shadeMin, -1},    // -1: by traversal mode, see srtRenderTiles
     {"prim_min", "SRT_PRIM_MIN", &Tunables::primMin, 12},
     {"hit_min", "SRT_HIT_MIN", &Tunables::hitMin, 24},
     {"fuse_min", "SRT_FUSE_MIN", &Tunables::fuseMin, 32},
-    {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, 64},
+    {"node_burst", "SRT_NODE_BURST", &Tunables::nodeBurst, -1},
     {"ploc_radius", "SRT_PLOC_RADIUS", &Tunables::plocRadius, 64},
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
-    {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, 4},  // round-2 sweep: 6 -> 4 is +3.5 % (profiles/r02/scheduler_sweep.txt)
+    {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
 };
 
@@ -963,13 +963,19 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.sppBase = a.spp / a.sppChunks;
   a.sppRem = a.spp % a.sppChunks;
   a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
-  a.shadeMin = ctx->tun.shadeMin;
+  // Scheduler defaults by traversal mode (profiles/r02/scheduler_sweep.txt).  FAITHFUL on cache-resident scenes:
+  // node bursts go on while half of their lanes are still at nodes, up to 64 visits, restarts at 24 waiting lanes
+  // (+6 % on the headline frame against 6/8, 32, 16).  The closest-hit traversal over the 64-byte records is bound by
+  // memory latency on large scenes and wants shorter bursts that give up sooner (10 M triangles: 87.6 against 77.8
+  // Msamples/s), and does not care on small ones.
+  const bool closestMode = p->traversal == SRT_TRAVERSE_CLOSEST;
+  a.shadeMin = ctx->tun.shadeMin >= 0 ? ctx->tun.shadeMin : (closestMode ? 16 : 24);
   a.primMin = ctx->tun.primMin;
   a.hitMin = ctx->tun.hitMin;
   a.fuseMin = ctx->tun.fuseMin;
-  a.nodeBurst = std::max(1, ctx->tun.nodeBurst);
+  a.nodeBurst = std::max(1, ctx->tun.nodeBurst > 0 ? ctx->tun.nodeBurst : (closestMode ? 32 : 64));
   a.primAgainMin = std::max(1, ctx->tun.primAgainMin);
-  a.keepEighths = std::min(8, std::max(0, ctx->tun.keepEighths));
+  a.keepEighths = std::min(8, ctx->tun.keepEighths >= 0 ? ctx->tun.keepEighths : (closestMode ? 6 : 4));
   a.queue = ctx->dQueue;
   a.stats = p->countStats ? ctx->dStats : nullptr;
   a.aov = p->countStats ? ctx->dAov : nullptr;

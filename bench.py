@@ -82,7 +82,11 @@ PMC_PASSES = [
     ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
     ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
             "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES"]),
+    # the vector-memory address unit (one TA per CU, in front of the vector L1): how busy the path of the node loads is
+    ("ta", ["TA_BUSY_avr", "TA_BUFFER_READ_WAVEFRONTS_sum"]),
+    ("ta_stall", ["TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"]),
 ]
+PMC_OPTIONAL = ("ta", "ta_stall")  # a pass the profiler refuses on this box is left out, the others still count
 
 
 def build_scene(srt, scene_name, builder):
@@ -210,6 +214,9 @@ def collect_pmc(args, workload, spp, timeout_s):
                                                   "--spp", str(spp), "--seed", str(args.seed), "--spp-chunks", str(args.spp_chunks)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             if r.returncode != 0:
+                if name in PMC_OPTIONAL:
+                    sys.stderr.write("bench.py: optional counter pass '%s' failed, left out\n" % name)
+                    continue
                 raise RuntimeError("rocprofv3 pass '%s' failed (rc %d): %s" % (name, r.returncode, r.stdout.decode(errors="replace")[-400:]))
             acc, cnt = {}, {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -220,6 +227,8 @@ def collect_pmc(args, workload, spp, timeout_s):
                     acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
                     cnt[c] = cnt.get(c, 0) + 1
             if not acc:
+                if name in PMC_OPTIONAL:
+                    continue
                 raise RuntimeError("rocprofv3 pass '%s' recorded no render-kernel dispatch" % name)
             for c in acc:
                 out[c] = acc[c] / cnt[c]
@@ -296,6 +305,23 @@ def roofline_block(bound, pmc, pmc_source, avg_kernel_ms, alg_bytes_per_launch, 
                   "valu_wave_instr_per_sample": round(pmc["SQ_INSTS_VALU"] / max(1, pmc.get("_samples", 1)), 2),
                   "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in pmc else None,
                   "salu_per_valu": round(pmc["SQ_INSTS_SALU"] / pmc["SQ_INSTS_VALU"], 4) if "SQ_INSTS_SALU" in pmc else None})
+    if pmc and "SQ_INSTS_VMEM_RD" in pmc:
+        # The other unit this kernel leans on: every node visit is two divergent 16-byte loads per lane through the
+        # CU's vector L1.  tools/ubench_tcp.hip (profiles/r02/ubench_tcp.txt) prices such a wave-instruction at
+        # 16 + 0.45 x (cache lines touched) cycles of that path; here is what the frame leaves per instruction.
+        ghz = r.get("clock_ghz") or info["clock_mhz"] / 1e3  # the clock measured above when the SQ pass has it
+        cu_cycles = info["cus"] * (pmc.get("_kernel_ms", avg_kernel_ms) * 1e-3) * ghz * 1e9
+        l1 = {"vmem_rd_wave_instr": int(pmc["SQ_INSTS_VMEM_RD"]),
+              "cu_cycles_per_vmem_rd_instr": round(cu_cycles / pmc["SQ_INSTS_VMEM_RD"], 2),
+              "ubench_cycles_per_divergent_dwordx4": {"64 lanes": 38.7, "38 lanes": 29.3, "16 lanes": 22.2,
+                                                       "source": "profiles/r02/ubench_tcp.txt, 16 KB table (L1 hits)"}}
+        if "TA_BUSY_avr" in pmc:
+            l1["ta_busy_frac"] = round(pmc["TA_BUSY_avr"] / (cu_cycles / info["cus"]), 4)
+        if "TA_ADDR_STALLED_BY_TC_CYCLES_sum" in pmc:
+            l1["ta_addr_stalled_by_l1_frac"] = round(pmc["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / cu_cycles, 4)
+        if "TA_DATA_STALLED_BY_TC_CYCLES_sum" in pmc:
+            l1["ta_data_stalled_by_l1_frac"] = round(pmc["TA_DATA_STALLED_BY_TC_CYCLES_sum"] / cu_cycles, 4)
+        r["l1_path"] = l1
     if traffic is not None:
         r["hbm_measured_frac"] = round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     r["note"] = ("frac = VALU issue fraction x lane utilisation (useful lane-operations / chip lane-operation peak); "

@@ -41,9 +41,14 @@ int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAo
  *           hit-step executions, hit-step lanes, restart-step executions, restart-step lanes, reserved }. */
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10);
 
+/* The most recent render-kernel launch: out4 = { 1 if the LDS-resident-tree variant ran (FAITHFUL, node array small
+ * enough for a CU's LDS; tunable "lds_tree" = 0 switches it off), workgroups, threads per workgroup, LDS bytes per
+ * workgroup }. */
+int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4);
+
 /* Per-context diagnostic tunables of the work distribution and the wave scheduler ("queues", "unit_tiles",
  * "tile_block", "shade_min", "prim_min", "hit_min", "fuse_min", "node_burst", "ploc_radius", "fast_div",
- * "prim_again_min", "keep_eighths", "chunk_scratch_mb": memory budget of the chunk-slot path of the exact chunk sum, 0 forces the atomic path).  Defaults come from the library (and, for the scheduler thresholds, from SRT_*
+ * "prim_again_min", "keep_eighths", "lds_tree", "chunk_scratch_mb": memory budget of the chunk-slot path of the exact chunk sum, 0 forces the atomic path).  Defaults come from the library (and, for the scheduler thresholds, from SRT_*
  * environment variables read ONCE at srtCreate); none of them changes the image
  * (tests/test_gpu_properties.py::test_image_independent_of_work_distribution).  "tile_block" has no
  * environment override: every rank and the host untile (tiles.py) must agree on it. */

@@ -22,8 +22,8 @@
 #include "srt_device.h"
 
 extern "C" {
-int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream);
-int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU);
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_render_occupancy(int traversal, int count, int ldsTree, size_t ldsBytes, int* blocksPerCU);
 int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream);
 int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
@@ -229,6 +229,7 @@ struct Tunables {
   int chunkScratchMb;
   int primAgainMin;
   int keepEighths;
+  int ldsTree;
 };
 
 struct SrtContext {
@@ -255,6 +256,8 @@ struct SrtContext {
   SrtAovRecord* dAov = nullptr;  // set only for the duration of srtRenderAov
   int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
+  DeviceBuffer attScratch;  // LDS-resident-tree kernel: the lanes' attenuation stacks (srt_render_kernel LDSTREE)
+  int32_t lastLaunch[4] = {0, 0, 0, 0};  // srtGetLaunchInfo
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
   SrtStats lastStats{};
@@ -322,6 +325,7 @@ const TunableName kTunables[] = {
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
     {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
+    {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 256},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -443,6 +447,7 @@ int srtDestroy(SrtContext* ctx) {
   (void)srtCommDestroy(ctx);
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
+  if (ctx->attScratch.p) (void)hipFree(ctx->attScratch.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
   if (ctx->dStats) (void)hipFree(ctx->dStats);
   if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -1006,17 +1011,40 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
       HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
     }
   }
-  const size_t lds = ldsBytesFor(ctx, p->maxBounce);
+  // FAITHFUL on a scene whose whole node array fits into a CU's LDS beside 1024 lanes' 16-bit traversal stacks: the
+  // LDS-resident-tree kernel (srt_render_kernel LDSTREE), one workgroup of 1024 threads per CU.  References must
+  // fit the 16-bit stack slots: node indices and primitive references below 2^15.
+  const size_t ldsTreeBytes = (size_t)ctx->scene.numNodes * 32 + (size_t)(ctx->scene.stackDepth + 2) * 1024 * sizeof(int16_t) + 16 * sizeof(int32_t);
+  // Trees of a few dozen nodes stay with the 256-thread kernel: their frames are shading-bound and lose 3 % to the
+  // big workgroup (4 waves per SIMD instead of 5, attenuation stack in global memory; profiles/r02/lds_tree.txt).
+  const bool ldsTree = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->tun.ldsTree > 0 && ctx->scene.numNodes >= ctx->tun.ldsTree && ldsTreeBytes <= 160 * 1024 &&
+                       ctx->scene.numNodes < 32767 && 2 * (int64_t)ctx->scene.numTris < 32766 && 2 * (int64_t)ctx->scene.numSpheres + 1 < 32766;
+  const size_t lds = ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   int perCU = 0;
-  if (srt_render_occupancy(p->traversal, p->countStats, lds, &perCU) != 0 || perCU < 1) perCU = 1;
-  // persistent waves: enough workgroups to fill every CU, never more than there is work (4 waves each)
-  int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * 4 - 1) / (SRT_TILE_PIXELS * 4));
+  if (srt_render_occupancy(p->traversal, p->countStats, ldsTree, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
+  const int wgWaves = ldsTree ? 16 : 4;
+  int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * wgWaves - 1) / (SRT_TILE_PIXELS * wgWaves));
   if (grid < 1) grid = 1;
+  if (ldsTree) {
+    const size_t need = (size_t)(3 * p->maxBounce + 3) * grid * 1024 * sizeof(float);
+    if (ctx->attScratch.bytes < need) {
+      if (ctx->attScratch.p) HIP_OK(ctx, hipFree(ctx->attScratch.p));
+      ctx->attScratch = DeviceBuffer();
+      HIP_OK(ctx, hipMalloc(&ctx->attScratch.p, need));
+      ctx->attScratch.bytes = need;
+    }
+    a.attScratch = static_cast<float*>(ctx->attScratch.p);
+  }
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  int rc = srt_launch_render(&a, p->traversal, p->countStats, grid, lds, stream);
+  ctx->lastLaunch[0] = ldsTree ? 1 : 0;
+  ctx->lastLaunch[1] = grid;
+  ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
+  ctx->lastLaunch[3] = (int32_t)lds;
+  int rc = srt_launch_render(&a, p->traversal, p->countStats, ldsTree, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;
@@ -1210,6 +1238,11 @@ static int srtRenderAovImpl(SrtContext* ctx, const SrtRenderParams* pIn, int32_t
 int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAovRecord* hOut) { SRT_GUARDED(ctx, srtRenderAovImpl(ctx, p, depth, hOut)); }
 
 /* include/srt_hip_test.h: sub-step profile of the counting variant's last launch */
+int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4) {
+  if (!ctx || !out4) return 1;
+  memcpy(out4, ctx->lastLaunch, sizeof ctx->lastLaunch);
+  return 0;
+}
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10) {
   if (!ctx || !out10) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));

@@ -110,6 +110,7 @@ struct RenderArgs {
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr
   SrtAovRecord* aov;          // counting variant only: per-pixel record of the ray at bounce aovDepth (srtRenderAov)
   int32_t aovDepth;
+  float* attScratch;          // LDS-resident-tree variant: [3 * maxBounce + 3][grid * 1024] attenuation slots in global memory
 };
 
 struct TraceArgs {

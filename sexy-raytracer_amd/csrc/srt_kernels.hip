@@ -29,11 +29,15 @@
 // No MFMA: there is no dense contraction on this path.
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "srt_device.h"
 
 #define SRT_BLOCK 256
+#define SRT_BLOCK_TREE 1024      // LDS-resident tree: one workgroup per CU
+#define SRT_TREE_WAVES_PER_SIMD 4
 #ifndef SRT_NODE_UNROLL
 #define SRT_NODE_UNROLL 4  // node visits per evaluation of the burst loop's exit test
 #endif
@@ -764,15 +768,34 @@ enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3, M_HIT = 4 };
 
 // SINGLE: the world list is one tree (the usual case, main.cpp:146) -- known at compile time, the per-visit
 // "next root of the world list?" test disappears from the node and primitive steps.
-template <bool CLOSEST, bool COUNT, bool SINGLE>
-__global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(const RenderArgs a) {
+//
+// LDSTREE (FAITHFUL, a scene whose whole node array fits): ONE workgroup of 1024 threads per CU keeps the node
+// records in LDS -- 160 KB per CU is the one memory on this chip that takes a wave's 64 scattered 32-byte reads
+// without going through the vector L1, whose address unit is the busiest unit of the 256-thread kernel (78 % of
+// the cycles on the headline frame; a divergent dwordx4 wave-load costs it 16 + 0.45 x lines cycles,
+// tools/ubench_tcp.hip, against ~11 cycles for the same two reads from LDS, tools/ubench_lds.hip).  To make room the
+// traversal stack holds 16-bit references (node INDEX or primitive reference; the node records are rewritten
+// to indices while they are copied in, so a visit's address is cur << 5) and the attenuation stack moves to
+// global memory (three coalesced stores per bounce).  Same records, same arithmetic, same decisions.
+template <bool CLOSEST, bool COUNT, bool SINGLE, bool LDSTREE>
+__global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT_TREE_WAVES_PER_SIMD : SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(
+    const RenderArgs a) {
+  static_assert(!(CLOSEST && LDSTREE), "the LDS-resident tree serves the FAITHFUL traversal");
+  constexpr int BLOCK = LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK;  // threads per workgroup = stride of the [slot][thread] arrays
+  // "no reference": what popping the empty stack yields.  LDSTREE: the 16-bit sentinel, sign-extended.
+  constexpr int32_t DONE = LDSTREE ? (int32_t)0xFFFF8000 : SRT_REF_DONE;
+  typedef typename std::conditional<LDSTREE, int16_t, int32_t>::type StackT;
   extern __shared__ int32_t lds[];
   // per-thread LDS slots, [slot][thread]: stackDepth+2 traversal slots (slot 0 holds a sentinel, the last
   // one is a spare for the node step's unconditional store), then 3*maxBounce attenuation floats and 3
-  // floats of terminal radiance
-  int32_t* const stackBase = lds + threadIdx.x;
-  *stackBase = SRT_REF_DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
-  float* attStack = reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * SRT_BLOCK + threadIdx.x);
+  // floats of terminal radiance.  LDSTREE: node records first, then the (16-bit) traversal slots.
+  char* const ldsTree = reinterpret_cast<char*>(lds);
+  const int treeBytes = LDSTREE ? a.scene.numNodes * 32 : 0;
+  StackT* const stackBase = reinterpret_cast<StackT*>(ldsTree + treeBytes) + threadIdx.x;
+  *stackBase = (StackT)DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
+  float* attStack = LDSTREE ? a.attScratch + (size_t)blockIdx.x * BLOCK + threadIdx.x
+                            : reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * BLOCK + threadIdx.x);
+  const int attStride = LDSTREE ? (int)gridDim.x * BLOCK : BLOCK;
   const int lane = threadIdx.x & 63;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
@@ -783,6 +806,19 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
   const __amdgpu_buffer_rsrc_t rsTexels = makeRsrc(sc.texels, sc.texelBytes);
   const bool singleRoot = SINGLE || sc.numWorld == 1;
+  if (LDSTREE) {
+    // node records into LDS, child references of nodes as indices (a 16-bit stack slot holds them; byte offset = index << 5)
+    float4* dst = reinterpret_cast<float4*>(ldsTree);
+    for (int i = threadIdx.x; i < sc.numNodes * 2; i += BLOCK) {
+      float4 v = bufLoad4(rsNodes, 16 * i);
+      const int r = __float_as_int(v.w);
+      if (r >= 0) v.w = __int_as_float(r >> 5);
+      dst[i] = v;
+    }
+    __syncthreads();
+  }
+  // a reference as the world list holds it -> as this kernel's lanes hold it
+  auto localRef = [&](int r) { return LDSTREE && r >= 0 ? r >> 5 : r; };
 
   unsigned long long cSamples = 0, cRays = 0, cNodes = 0, cBox = 0, cTri = 0, cSph = 0, cShTri = 0, cTex = 0;
   // scheduler profile (COUNT variant only; wave-uniform)
@@ -800,7 +836,8 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   // A wave that finds its queue drained moves to the queue with the most items left (steals), preferring
   // the queues of its own XCD; when none has any left its idle lanes leave.  The wave's current queue
   // lives in one LDS word (-1: everything drained) so that every lane sees it whichever lanes pulled last.
-  int32_t* waveQueue = lds + (a.scene.stackDepth + 2 + 3 * a.maxBounce + 3) * SRT_BLOCK + (threadIdx.x >> 6);
+  int32_t* waveQueue = LDSTREE ? reinterpret_cast<int32_t*>(ldsTree + treeBytes + (a.scene.stackDepth + 2) * BLOCK * (int)sizeof(StackT)) + (threadIdx.x >> 6)
+                               : lds + (a.scene.stackDepth + 2 + 3 * a.maxBounce + 3) * BLOCK + (threadIdx.x >> 6);
   const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
   if (lane == 0) *waveQueue = qHome;
   const int unitItems = a.unitTiles * a.sppChunks * SRT_TILE_PIXELS;
@@ -824,12 +861,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
   rng.state = 0;
   int depth = 0;
   // traversal state (hittableList::hit over the world list + bvhNode::hit as a DFS; see traverse())
-  int cur = SRT_REF_DONE, w = 0, hitRef = SRT_REF_DONE;
-  int32_t* sptr = stackBase;  // top of this lane's stack of pending references (slot 0 = sentinel)
+  int cur = DONE, w = 0, hitRef = DONE;
+  StackT* sptr = stackBase;  // top of this lane's stack of pending references (slot 0 = sentinel)
   auto atNode = [&]() { return cur >= 0; };
-  auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)SRT_REF_DONE; };
-  auto atHit = [&]() { return cur == SRT_REF_DONE && hitRef != SRT_REF_DONE; };
-  auto atRestart = [&]() { return cur == SRT_REF_DONE && hitRef == SRT_REF_DONE && alive; };
+  auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)DONE; };
+  auto atHit = [&]() { return cur == DONE && hitRef != DONE; };
+  auto atRestart = [&]() { return cur == DONE && hitRef == DONE && alive; };
   float closest = SRT_INF, rayA = 0.0f;
   // slab test per ray (boxHitApprox): refined reciprocals of ray.d, m = -o * rcpD, absolute tolerance
   V3 rcpD = mk(0.0f, 0.0f, 0.0f), negOR = mk(0.0f, 0.0f, 0.0f);
@@ -849,7 +886,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     r.valid = 1;
     r.prim = SRT_NO_HIT;
     r.t = 0.0f;
-    if (ref != SRT_REF_DONE) {
+    if (ref != DONE) {
       const int pr = ~ref;
       r.prim = (pr & 1) ? sc.sphPrimId[pr >> 1] : sc.triPrimId[pr >> 1];
       r.t = closest;
@@ -862,9 +899,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     a.aov[pixel] = r;
   };
   auto popNext = [&](int next) {  // next = *sptr, read early by the caller: the sentinel when nothing is pending
-    sptr -= SRT_BLOCK;
-    if (!SINGLE && !singleRoot && next == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
-      next = sc.world[w];
+    sptr -= BLOCK;
+    if (!SINGLE && !singleRoot && next == DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+      next = localRef(sc.world[w]);
       if (CLOSEST && next >= 0) next <<= 1;
       sptr = stackBase;
     }
@@ -886,10 +923,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
     slabSetup(ray.o, rcpD, certified, negOR, slabTol);
     if (CLOSEST) dirNeg = (ray.d.x < 0.0f ? 1 : 0) | (ray.d.y < 0.0f ? 2 : 0) | (ray.d.z < 0.0f ? 4 : 0);
     closest = SRT_INF;
-    hitRef = SRT_REF_DONE;
+    hitRef = DONE;
     sptr = stackBase;
     w = 0;
-    cur = sc.world[0];
+    cur = localRef(sc.world[0]);
     if (CLOSEST && cur >= 0) cur <<= 1;  // node references of the closest-hit traversal address the 64-byte records
     pend = 1;  // a miss unless a hit-shading step says otherwise
   };
@@ -1008,12 +1045,12 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
               if (COUNT) cBox += (hl ? 1 : 0) + (hr ? 1 : 0);
               const bool both = hl && hr, leftFirst = !hr || (hl && !(tr < tl));
               const int nearRef = leftFirst ? left : right, farRef = leftFirst ? right : left;
-              sptr[SRT_BLOCK] = farRef;  // the slot above the top is free; live only if sptr is bumped
+              sptr[BLOCK] = (StackT)farRef;  // the slot above the top is free; live only if sptr is bumped
               int move = (hl || hr) ? (both ? 1 : 0) : -1;
               asm("" : "+v"(move));
-              sptr += move * SRT_BLOCK;
+              sptr += move * BLOCK;
               cur = (hl || hr) ? nearRef : top;
-              if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {
+              if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
                 cur = sc.world[w] >= 0 ? sc.world[w] << 1 : sc.world[w];
                 sptr = stackBase;
               }
@@ -1021,7 +1058,14 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
             return;
           }
           if (atNode()) {
-            float4 n0 = bufLoad4(rsNodes, cur), n1 = bufLoad4(rsNodes, cur + 16);  // node references are byte offsets
+            float4 n0, n1;
+            if (LDSTREE) {  // node references are indices into the LDS copy
+              n0 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5));
+              n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
+            } else {  // node references are byte offsets
+              n0 = bufLoad4(rsNodes, cur);
+              n1 = bufLoad4(rsNodes, cur + 16);
+            }
             const int axis = CLOSEST ? sc.nodeAxis[cur >> 5] : 3;  // issued with the node record, used after the box test
             const int top = *sptr;  // pending reference, or the sentinel: read while the node record is on its way
 #if defined(SRT_PROBE_LOAD128)
@@ -1048,7 +1092,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
                 right = tmp;
               }
             }
-            sptr[SRT_BLOCK] = right;   // the slot above the top is free; it becomes live only if sptr is bumped
+            sptr[BLOCK] = (StackT)right;   // the slot above the top is free; it becomes live only if sptr is bumped
             // hit: descend left, right stays pending (a single-object leaf has left == right: nothing pending);
             // miss: take the pending reference.  The stack cannot overflow: its capacity (stackDepth slots + a
             // spare) is the tree's maximum number of pending references, computed or verified at upload.
@@ -1066,10 +1110,10 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
               if (__float_as_uint(pv) == 0x7fc12345u) move = 0;
             }
 #endif
-            sptr += move * SRT_BLOCK;  // one shift-add
+            sptr += move * BLOCK;  // one shift-add
             cur = hitBox ? left : top;
-            if (!SINGLE && !singleRoot && cur == SRT_REF_DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
-              cur = sc.world[w];
+            if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
+              cur = localRef(sc.world[w]);
               sptr = stackBase;
             }
           }
@@ -1106,9 +1150,9 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         bool done = true;
         if (scattered) {
           // emitted is (0,0,0) for every scattering material (material.h:18-20)
-          attStack[(3 * depth + 0) * SRT_BLOCK] = att.x;
-          attStack[(3 * depth + 1) * SRT_BLOCK] = att.y;
-          attStack[(3 * depth + 2) * SRT_BLOCK] = att.z;
+          attStack[(3 * depth + 0) * attStride] = att.x;
+          attStack[(3 * depth + 1) * attStride] = att.y;
+          attStack[(3 * depth + 2) * attStride] = att.z;
           ray = next;
           depth++;
           done = depth >= a.maxBounce;  // main.cpp:36-37: out of bounces -> black
@@ -1116,11 +1160,11 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
         }
         if (done) {
           // the path ends here: leave its terminal radiance for the restart step
-          attStack[(3 * a.maxBounce + 0) * SRT_BLOCK] = terminal.x;
-          attStack[(3 * a.maxBounce + 1) * SRT_BLOCK] = terminal.y;
-          attStack[(3 * a.maxBounce + 2) * SRT_BLOCK] = terminal.z;
+          attStack[(3 * a.maxBounce + 0) * attStride] = terminal.x;
+          attStack[(3 * a.maxBounce + 1) * attStride] = terminal.y;
+          attStack[(3 * a.maxBounce + 2) * attStride] = terminal.z;
           pend = 2;
-          hitRef = SRT_REF_DONE;  // shaded: the lane now waits for a restart step
+          hitRef = DONE;  // shaded: the lane now waits for a restart step
         } else {
           startTraversal();
         }
@@ -1152,16 +1196,16 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_RENDER_WAVES_PER_SIMD) void srt_rend
       }
       if (atRestart()) {
         if (pend != 0) {
-          if (COUNT && a.aov && pend == 1 && depth == a.aovDepth && s == a.sampleFirst) writeAov(SRT_REF_DONE);
+          if (COUNT && a.aov && pend == 1 && depth == a.aovDepth && s == a.sampleFirst) writeAov(DONE);
           V3 L = background;  // main.cpp:39-40
           if (pend == 2)
-            L = mk(attStack[(3 * a.maxBounce + 0) * SRT_BLOCK], attStack[(3 * a.maxBounce + 1) * SRT_BLOCK],
-                   attStack[(3 * a.maxBounce + 2) * SRT_BLOCK]);
+            L = mk(attStack[(3 * a.maxBounce + 0) * attStride], attStack[(3 * a.maxBounce + 1) * attStride],
+                   attStack[(3 * a.maxBounce + 2) * attStride]);
           pend = 0;
           // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
           for (int j = depth - 1; j >= 0; --j) {
-            float ax = attStack[(3 * j + 0) * SRT_BLOCK], ay = attStack[(3 * j + 1) * SRT_BLOCK],
-                  az = attStack[(3 * j + 2) * SRT_BLOCK];
+            float ax = attStack[(3 * j + 0) * attStride], ay = attStack[(3 * j + 1) * attStride],
+                  az = attStack[(3 * j + 2) * attStride];
             L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
           }
           acc = acc + L;  // main.cpp:217
@@ -1429,21 +1473,36 @@ extern "C" {
 
 namespace {
 typedef void (*RenderKernel)(const RenderArgs);
-RenderKernel renderVariant(const RenderArgs* a, int traversal, int count) {
+RenderKernel renderVariant(const RenderArgs* a, int traversal, int count, int ldsTree) {
   const bool closest = traversal == SRT_TRAVERSE_CLOSEST, single = a == nullptr || a->scene.numWorld == 1;
-  if (count) return closest ? srt_render_kernel<true, true, false> : srt_render_kernel<false, true, false>;
-  if (single) return closest ? srt_render_kernel<true, false, true> : srt_render_kernel<false, false, true>;
-  return closest ? srt_render_kernel<true, false, false> : srt_render_kernel<false, false, false>;
+  if (ldsTree && !closest) {
+    if (count) return srt_render_kernel<false, true, false, true>;
+    return single ? srt_render_kernel<false, false, true, true> : srt_render_kernel<false, false, false, true>;
+  }
+  if (count) return closest ? srt_render_kernel<true, true, false, false> : srt_render_kernel<false, true, false, false>;
+  if (single) return closest ? srt_render_kernel<true, false, true, false> : srt_render_kernel<false, false, true, false>;
+  return closest ? srt_render_kernel<true, false, false, false> : srt_render_kernel<false, false, false, false>;
 }
 }  // namespace
 
-int srt_launch_render(const RenderArgs* a, int traversal, int count, int grid, size_t ldsBytes, hipStream_t stream) {
-  hipLaunchKernelGGL(renderVariant(a, traversal, count), dim3(grid), dim3(SRT_BLOCK), ldsBytes, stream, *a);
+// ldsTree: the LDS-resident-tree variant (FAITHFUL): workgroups of SRT_BLOCK_TREE threads, up to 160 KB of LDS each
+int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream) {
+  const RenderKernel k = renderVariant(a, traversal, count, ldsTree);
+  if (ldsBytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(ldsTree ? SRT_BLOCK_TREE : SRT_BLOCK), ldsBytes, stream, *a);
   return (int)hipGetLastError();
 }
 
-int srt_render_occupancy(int traversal, int count, size_t ldsBytes, int* blocksPerCU) {
-  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, renderVariant(nullptr, traversal, count), SRT_BLOCK, ldsBytes);
+int srt_render_occupancy(int traversal, int count, int ldsTree, size_t ldsBytes, int* blocksPerCU) {
+  const RenderKernel k = renderVariant(nullptr, traversal, count, ldsTree);
+  if (ldsBytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k, ldsTree ? SRT_BLOCK_TREE : SRT_BLOCK, ldsBytes);
 }
 
 int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream) {

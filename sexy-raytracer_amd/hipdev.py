@@ -26,7 +26,7 @@ EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostR
            "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtRenderAov"]
+TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtGetLaunchInfo", "srtRenderAov"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -61,6 +61,7 @@ lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtGetShadeProfile.argtypes = [_vp, _vp]
+lib.srtGetLaunchInfo.argtypes = [_vp, _vp]
 lib.srtRenderAov.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), C.c_int32, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]
@@ -256,6 +257,12 @@ class Context:
         out = np.zeros(10, np.uint64)
         self._check(lib.srtGetShadeProfile(self.h, out.ctypes.data))
         return [int(x) for x in out]
+
+    def launch_info(self):
+        """The most recent render launch: {"lds_tree", "workgroups", "threads", "lds_bytes"} (include/srt_hip_test.h)."""
+        out = np.zeros(4, np.int32)
+        self._check(lib.srtGetLaunchInfo(self.h, out.ctypes.data))
+        return {"lds_tree": bool(out[0]), "workgroups": int(out[1]), "threads": int(out[2]), "lds_bytes": int(out[3])}
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -52,3 +52,14 @@ def ctx(dev):
 @pytest.fixture(scope="session")
 def camera(dev, abi):
     return dev.make_camera(abi.default_camera_params())
+
+
+@pytest.fixture(params=[1, 0], ids=["lds_tree", "l1_nodes"])
+def node_path(request, ctx):
+    """Both node paths of the FAITHFUL render kernel: the LDS-resident-tree variant (one workgroup of 1024 threads per
+    CU, the default for scenes whose node array fits a CU's LDS) and the 256-thread kernel that reads the node
+    records through the vector L1 (tunable lds_tree = 0; what larger scenes get)."""
+    default = ctx.get_tunable("lds_tree")
+    ctx.set_tunable("lds_tree", request.param)  # 1: every tree that fits, however small
+    yield request.param
+    ctx.set_tunable("lds_tree", default)

@@ -160,7 +160,7 @@ def test_trace_ray_edge_cases(ctx, oracle, abi, scenes):
 
 
 @pytest.mark.parametrize("name", SCENES)
-def test_render_matches_golden_fixture(ctx, abi, scenes, camera, name):
+def test_render_matches_golden_fixture(ctx, abi, scenes, camera, name, node_path):
     g = np.load(os.path.join(GOLD, "render_%s.npz" % name))
     ctx.upload_scene(scenes[name])
     ctx.set_camera(camera)
@@ -174,7 +174,7 @@ def test_render_matches_golden_fixture(ctx, abi, scenes, camera, name):
         assert st[k] == want[k], k
 
 
-def test_render_config1_vs_oracle(ctx, oracle, abi, scenes, camera):
+def test_render_config1_vs_oracle(ctx, oracle, abi, scenes, camera, node_path):
     """BASELINE config 1 exactly: 3 spheres + ground, 426x240 (240p), 64 spp, 8 bounces."""
     sb = scenes["spheres"]
     ctx.upload_scene(sb)
@@ -194,7 +194,7 @@ def test_render_config1_vs_oracle(ctx, oracle, abi, scenes, camera):
 
 
 @pytest.mark.parametrize("name,spp,mb", [("iron", 16, 4), ("masterchief", 16, 4)])
-def test_render_240p_vs_oracle(ctx, oracle, abi, scenes, camera, name, spp, mb):
+def test_render_240p_vs_oracle(ctx, oracle, abi, scenes, camera, name, spp, mb, node_path):
     sb = scenes[name]
     ctx.upload_scene(sb)
     ctx.set_camera(camera)
@@ -208,7 +208,7 @@ def test_render_240p_vs_oracle(ctx, oracle, abi, scenes, camera, name, spp, mb):
         assert_counter(st[k], want_st[k], k)
 
 
-def test_sphere_field_vs_oracle(ctx, oracle, abi, srt, camera):
+def test_sphere_field_vs_oracle(ctx, oracle, abi, srt, camera, node_path):
     """the 22x22 sphere field main.cpp:92-122 keeps commented out -- 480-odd small spheres,
     most of them moving (sphere.h:47-52), fuzzy metals and glass, in one bvhNode: same tree as the oracle,
     render and counters against the oracle with identical counter-RNG keys."""
@@ -263,7 +263,7 @@ def test_scatter_known_answers(ctx, oracle, abi, scenes):
 
 
 @pytest.mark.parametrize("name,bounces", [("masterchief", 4), ("spheres", 8), ("iron", 4)])
-def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, camera, name, bounces):
+def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, camera, name, bounces, node_path):
     """srtTraceRays runs its own kernel; this pins the RENDER kernel's node / primitive steps ray by ray
     (VERDICT r1 item 4): srtRenderAov records, per pixel, the ray srt_render_kernel traced at bounce
     `depth` of the first sample and the hit, t and counters its scheduler-driven traversal (one-FMA slab

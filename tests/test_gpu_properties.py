@@ -164,7 +164,7 @@ def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
         assert np.abs(rgba.astype(int) - want_rgba.astype(int)).max() <= 1
 
 
-def test_bounce_limits(ctx, abi, srt, camera):
+def test_bounce_limits(ctx, abi, srt, camera, node_path):
     ctx.upload_scene(srt.scenes.scene_spheres())
     ctx.set_camera(camera)
     p = abi.default_render_params(64, 36, 2, 0, seed=1)
@@ -217,7 +217,7 @@ def _world_variants(abi):
 
 
 @pytest.mark.parametrize("variant", ["list", "two_bvh", "moving", "textures"])
-def test_world_and_material_variants_vs_oracle(ctx, oracle, abi, camera, variant):
+def test_world_and_material_variants_vs_oracle(ctx, oracle, abi, camera, variant, node_path):
     sb = _world_variants(abi)[variant]
     ctx.upload_scene(sb)
     ctx.set_camera(camera)
@@ -538,3 +538,39 @@ def test_native_gather_one_rank_and_argument_errors(dev, abi, srt, camera):
         c.comm_init(dev.comm_unique_id(), 1, 0)              # can be set up again after destroy
     finally:
         c.close()
+
+
+def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camera):
+    """Scenes whose node array fits a CU's LDS render through the LDS-resident-tree variant (one workgroup of 1024
+    threads per CU, 16-bit traversal stacks, attenuation stack in global memory); larger ones and lds_tree = 0
+    through the 256-thread kernel.  Same records, same arithmetic: identical accumulators, bit for bit."""
+    import torch
+    W, H = 320, 180
+    default = ctx.get_tunable("lds_tree")
+    assert default > 1  # a node count: smaller trees stay with the 256-thread kernel
+    for name, spp, mb in (("masterchief", 8, 4), ("spheres", 8, 8), ("iron", 4, 4)):
+        ctx.upload_scene(srt.scenes.SCENES[name]())
+        ctx.set_camera(camera)
+        images = {}
+        for tree in (1, 0):
+            ctx.set_tunable("lds_tree", tree)
+            try:
+                local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+                p = abi.default_render_params(W, H, spp, mb, seed=3)
+                ctx.render_tiles(p, local.data_ptr(), None)
+                torch.cuda.synchronize()
+                info = ctx.launch_info()
+                assert info["lds_tree"] == bool(tree), (name, tree, info)
+                assert info["threads"] == (1024 if tree else 256)
+                assert info["lds_bytes"] <= 160 * 1024
+                images[tree] = local.cpu().numpy()
+            finally:
+                ctx.set_tunable("lds_tree", default)
+        assert np.array_equal(images[1].view(np.uint32), images[0].view(np.uint32)), name
+    # a tree that does not fit: 40 000 triangles -> ~40 000 nodes, 1.3 MB
+    ctx.upload_scene(srt.scenes.scene_soup(40000, seed=5, extent=6.0, size=0.1))
+    ctx.set_camera(camera)
+    local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+    ctx.render_tiles(abi.default_render_params(W, H, 2, 4, seed=3), local.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert not ctx.launch_info()["lds_tree"]

@@ -257,6 +257,8 @@ struct SrtContext {
   int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
   DeviceBuffer attScratch;  // LDS-resident-tree kernel: the lanes' attenuation stacks (srt_render_kernel LDSTREE)
+  DeviceBuffer tileTable;   // RenderArgs::tileXY for the image size and tile order below
+  int32_t tileTableKey[3] = {0, 0, 0};
   int32_t lastLaunch[4] = {0, 0, 0, 0};  // srtGetLaunchInfo
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
@@ -448,6 +450,7 @@ int srtDestroy(SrtContext* ctx) {
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
   if (ctx->attScratch.p) (void)hipFree(ctx->attScratch.p);
+  if (ctx->tileTable.p) (void)hipFree(ctx->tileTable.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
   if (ctx->dStats) (void)hipFree(ctx->dStats);
   if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -903,6 +906,7 @@ static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
   if (!ctx->haveCamera) return fail(ctx, "render: no camera set");
   if (p->imageWidth < 2 || p->imageHeight < 2) return fail(ctx, "render: image must be at least 2x2 (u,v divide by W-1,H-1)");
+  if (p->imageWidth > 65535 * SRT_TILE_W || p->imageHeight > 65535 * SRT_TILE_H) return fail(ctx, "render: image larger than 65535 tiles a side");
   if (p->spp < 1) return fail(ctx, "render: spp must be >= 1");
   if (p->sampleFirst < 0 || (int64_t)p->sampleFirst + p->spp > 0x7fffffff) return fail(ctx, "render: bad sample range");
   if (p->maxBounce < 0 || p->maxBounce > SRT_MAX_BOUNCE) return fail(ctx, "render: maxBounce must be in [0,%d]", SRT_MAX_BOUNCE);
@@ -968,6 +972,27 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.sppBase = a.spp / a.sppChunks;
   a.sppRem = a.spp % a.sppChunks;
   a.numUnits = (a.numLocalTiles + a.unitTiles - 1) / a.unitTiles;
+  a.unitGroups = a.unitTiles * a.sppChunks;
+  a.rcpUnitGroups = 1.0f / (float)a.unitGroups;
+  a.rcpChunks = 1.0f / (float)a.sppChunks;
+  if (ctx->tileTableKey[0] != p->imageWidth || ctx->tileTableKey[1] != p->imageHeight || ctx->tileTableKey[2] != a.tileBlock || !ctx->tileTable.p) {
+    // the tile order as a table (once per image size): the kernel's restart step looks a tile up instead of dividing
+    std::vector<uint32_t> table((size_t)a.numTiles);
+    for (int32_t i = 0; i < a.numTiles; ++i) {
+      int tx, ty;
+      srtTileFromOrder(i, a.tilesX, a.tilesY, a.tileBlock, tx, ty);
+      table[i] = (uint32_t)tx | (uint32_t)ty << 16;
+    }
+    if (ctx->tileTable.p) HIP_OK(ctx, hipFree(ctx->tileTable.p));
+    ctx->tileTable = DeviceBuffer();
+    HIP_OK(ctx, hipMalloc(&ctx->tileTable.p, std::max<size_t>(table.size() * 4, 16)));
+    ctx->tileTable.bytes = table.size() * 4;
+    HIP_OK(ctx, hipMemcpy(ctx->tileTable.p, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    ctx->tileTableKey[0] = p->imageWidth;
+    ctx->tileTableKey[1] = p->imageHeight;
+    ctx->tileTableKey[2] = a.tileBlock;
+  }
+  a.tileXY = static_cast<const uint32_t*>(ctx->tileTable.p);
   // Scheduler defaults by traversal mode (profiles/r02/scheduler_sweep.txt).  FAITHFUL on cache-resident scenes:
   // node bursts go on while half of their lanes are still at nodes, up to 64 visits, restarts at 24 waiting lanes
   // (+6 % on the headline frame against 6/8, 32, 16).  The closest-hit traversal over the 64-byte records is bound by

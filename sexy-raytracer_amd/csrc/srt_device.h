@@ -111,6 +111,11 @@ struct RenderArgs {
   SrtAovRecord* aov;          // counting variant only: per-pixel record of the ray at bounce aovDepth (srtRenderAov)
   int32_t aovDepth;
   float* attScratch;          // LDS-resident-tree variant: [3 * maxBounce + 3][grid * 1024] attenuation slots in global memory
+  // work-item decomposition without divisions (restart step): groups of 64 items per unit, float reciprocals of
+  // unitGroups and sppChunks, and srtTileFromOrder as a table over the image's tiles (tx | ty << 16)
+  int32_t unitGroups;
+  float rcpUnitGroups, rcpChunks;
+  const uint32_t* tileXY;
 };
 
 struct TraceArgs {

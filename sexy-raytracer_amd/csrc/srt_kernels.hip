@@ -1262,18 +1262,35 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
             // nothing from this queue: an empty item; pulls again from the new queue on the next restart step
             s = sEnd = 0;
           } else {
-            // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk
-            // plain divisions: replacing these seven by multiply-high forms with launch-constant magic numbers
-            // measured 3 % SLOWER on the headline frame (3297 against 3401 Msamples/s, same box,
-            // profiles/r02/bisect_divisions.txt) -- the item decomposition runs once per 78 samples and the shorter
-            // code changed the register allocation of the steps around it for the worse
-            const int u = idx / unitItems, inUnit = idx - u * unitItems;
-            const int group = inUnit >> 6, ln = inUnit & 63;
-            const int tileInUnit = group / a.sppChunks, chunk = group - tileInUnit * a.sppChunks;
+            // idx -> (local tile, chunk, pixel of the tile); 64 consecutive items = one tile, one chunk.
+            // No integer divisions here: a wave runs this branch whenever ANY of its restarting lanes has finished an
+            // item (7 restart steps out of 10 on the headline frame), and the seven divisions of the plain
+            // decomposition were ~270 of its ~350 VALU instructions.  The two quotients come from float reciprocals
+            // computed on the host (off by at most one: group < 2^25, quotients < 2^20; corrected with the exact
+            // integer remainder), the tile's place in the blocked order from a table (RenderArgs::tileXY).
+            const int group = idx >> 6, ln = idx & 63;  // unitItems is a multiple of 64
+            int u = (int)((float)group * a.rcpUnitGroups);
+            int inUnit = group - u * a.unitGroups;
+            if (inUnit < 0) {
+              u--;
+              inUnit += a.unitGroups;
+            } else if (inUnit >= a.unitGroups) {
+              u++;
+              inUnit -= a.unitGroups;
+            }
+            int tileInUnit = (int)((float)inUnit * a.rcpChunks);
+            int chunk = inUnit - tileInUnit * a.sppChunks;
+            if (chunk < 0) {
+              tileInUnit--;
+              chunk += a.sppChunks;
+            } else if (chunk >= a.sppChunks) {
+              tileInUnit++;
+              chunk -= a.sppChunks;
+            }
             const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
             const int tile = a.tileFirst + localTile * a.tileStride;
-            int tx, ty;
-            srtTileFromOrder(tile < a.numTiles ? tile : 0, a.tilesX, a.tilesY, a.tileBlock, tx, ty);
+            const uint32_t txy = a.tileXY[tile < a.numTiles ? tile : 0];  // srtTileFromOrder(tile): tx | ty << 16
+            const int tx = (int)(txy & 0xffffu), ty = (int)(txy >> 16);
             px = tx * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
             py = ty * SRT_TILE_H + (ln >> 3);
             pixel = (uint32_t)(py * a.imageWidth + px);

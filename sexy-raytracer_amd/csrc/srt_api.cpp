@@ -327,7 +327,7 @@ const TunableName kTunables[] = {
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
     {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
-    {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 256},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
+    {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 1},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -681,6 +681,59 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
     }
     if (texels.size() > (size_t)0x7fffff00) return fail(ctx, "scene: more than 2 GiB of texels");
   }
+  // ---- the material's flags ride in every primitive's material word (srt_device.h SRT_MAT_FLAGS_SHIFT), and the hit
+  // step's 128-byte shading records (srt_kernels.hip shade)
+  if (d->numMaterials > SRT_MAT_INDEX_MASK) return fail(ctx, "scene: more than %d materials", SRT_MAT_INDEX_MASK);
+  auto withFlags = [&](float& word) {
+    int32_t bits;
+    memcpy(&bits, &word, 4);
+    const int32_t m = bits & SRT_MAT_INDEX_MASK;
+    if (m < d->numMaterials) {
+      const DevMaterial& dm = mats[m];
+      const bool textured = dm.type == SRT_MAT_PBR && (dm.albedoTex >= 0 || dm.normalTex >= 0 || dm.metallicTex >= 0 || dm.roughnessTex >= 0);
+      bits |= (dm.flags & 3) << SRT_MAT_FLAGS_SHIFT | ((dm.type & 3) | (textured ? SRT_MAT_TEXTURED : 0)) << SRT_MAT_TYPE_SHIFT;
+    }
+    memcpy(&word, &bits, 4);
+  };
+  for (int i = 0; i < d->numTriangles; ++i) withFlags(triShade[4 * (size_t)i + 3].w);
+  for (int i = 0; i < d->numSpheres; ++i) withFlags(spheres[3 * (size_t)i + 1].w);
+  std::vector<uint4> shadeRecs((size_t)8 * d->numMaterials, make_uint4(0, 0, 0, 0));
+  for (int i = 0; i < d->numMaterials; ++i) {
+    const DevMaterial& m = mats[i];
+    auto f2u = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    uint4* r = &shadeRecs[(size_t)8 * i];
+    const bool textured = m.type == SRT_MAT_PBR && (m.albedoTex >= 0 || m.normalTex >= 0 || m.metallicTex >= 0 || m.roughnessTex >= 0);
+    r[0] = make_uint4((uint32_t)((m.type & 3) | (textured ? SRT_MAT_TEXTURED : 0)), (uint32_t)m.flags, f2u(m.metalness), f2u(m.roughness));
+    r[1] = make_uint4(f2u(m.albedo[0]), f2u(m.albedo[1]), f2u(m.albedo[2]), f2u(m.albedo[3]));
+    const int32_t ids[4] = {m.albedoTex, m.normalTex, m.metallicTex, m.roughnessTex};
+    // +32: the emit texture of a light, in full
+    if (m.type == SRT_MAT_LIGHT && ids[0] >= 0) {
+      const DevTexture& t = texs[ids[0]];
+      if (t.kind == SRT_TEX_SOLID)
+        r[2] = make_uint4(1, f2u(t.color[0]), f2u(t.color[1]), f2u(t.color[2]));
+      else if (t.kind == SRT_TEX_IMAGE && t.width == 0)
+        r[2] = make_uint4(1, f2u(1.0f), f2u(0.0f), f2u(1.0f));  // failed load: magenta (texture.h:130-131)
+      else if (t.kind == SRT_TEX_IMAGE && t.bpp >= 3)
+        r[2] = make_uint4(2, (uint32_t)t.width, (uint32_t)t.height, (uint32_t)t.offset);
+      else
+        r[2] = make_uint4(3, (uint32_t)ids[0], 0, 0);  // checker, 1- and 2-byte images: texValue
+    }
+    // +48, +64: the four pbr slots, two dwords each
+    uint32_t packed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) {
+      if (ids[k] < 0) continue;  // mode 0: no texture
+      const DevTexture& t = texs[ids[k]];
+      if (t.kind == SRT_TEX_IMAGE && t.bpp >= 3 && t.width > 0 && t.width < 32768 && t.height < 32768) {
+        packed[2 * k] = 2u | (uint32_t)t.width << 2 | (uint32_t)t.height << 17;
+        packed[2 * k + 1] = (uint32_t)t.offset;
+      } else {
+        packed[2 * k] = 3u;  // everything else goes through texValue on the id
+        packed[2 * k + 1] = (uint32_t)ids[k];
+      }
+    }
+    r[3] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    r[4] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+  }
   // ---- triangle records in tree order.  Device arrays were filled in the scene's own triangle order; a tree's
   // leaves reference them at random (a mesh's index order has nothing to do with the median splits), and with
   // millions of triangles every test is then a 48-byte gather from a cold place.  Renumber the triangles by
@@ -742,7 +795,7 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   memset(&s, 0, sizeof s);
   if (uploadVec(ctx, nodeAxis, &s.nodeAxis, 64) || uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
       uploadVec(ctx, spheres, &s.spheres) || uploadVec(ctx, triPrimId, &s.triPrimId) ||
-      uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) ||
+      uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) || uploadVec(ctx, shadeRecs, &s.shadeRecs) ||
       uploadVec(ctx, texs, &s.textures) || uploadVec(ctx, texels, &s.texels, 64))
     return 1;
   ctx->hostTriPrimId = triPrimId;
@@ -807,6 +860,7 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   s.numNodes = (int32_t)(nodes.size() / 2);
   s.numTris = d->numTriangles;
   s.numSpheres = d->numSpheres;
+  s.numMaterials = d->numMaterials;
   // fastDiv's operand certificate for the box coordinates (srt_kernels.hip): 0 or 2^-77 <= |c| <= 2^30
   s.fastDivScene = ctx->tun.fastDiv;
   for (const float4& v : nodes)
@@ -1040,8 +1094,8 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   // LDS-resident-tree kernel (srt_render_kernel LDSTREE), one workgroup of 1024 threads per CU.  References must
   // fit the 16-bit stack slots: node indices and primitive references below 2^15.
   const size_t ldsTreeBytes = (size_t)ctx->scene.numNodes * 32 + (size_t)(ctx->scene.stackDepth + 2) * 1024 * sizeof(int16_t) + 16 * sizeof(int32_t);
-  // Trees of a few dozen nodes stay with the 256-thread kernel: their frames are shading-bound and lose 3 % to the
-  // big workgroup (4 waves per SIMD instead of 5, attenuation stack in global memory; profiles/r02/lds_tree.txt).
+  // (Even trees of a few dozen nodes gain: their frames are shading-bound, and the 128-register kernel keeps a hit's
+  // texel loads in flight together where the 96-register one spills, profiles/r02/lds_tree.txt.)
   const bool ldsTree = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->tun.ldsTree > 0 && ctx->scene.numNodes >= ctx->tun.ldsTree && ldsTreeBytes <= 160 * 1024 &&
                        ctx->scene.numNodes < 32767 && 2 * (int64_t)ctx->scene.numTris < 32766 && 2 * (int64_t)ctx->scene.numSpheres + 1 < 32766;
   const size_t lds = ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);

@@ -22,6 +22,12 @@
 #define SRT_NODE_INDEX(ref) ((int32_t)(ref) >> 5)
 #define SRT_MAX_NODES (1 << 25) /* byte offsets (index * 64 in the closest-hit records) stay below 2^31 */
 #define SRT_MAX_QUEUES 64
+// a primitive's material word: material index, the material's type (SRT_MAT_*) and SRT_MAT_NEEDS_* flags,
+// (spheres) bit 30 = moving
+#define SRT_MAT_INDEX_MASK 0x00ffffff
+#define SRT_MAT_TYPE_SHIFT 24   /* four bits: SRT_MAT_* (two bits) | SRT_MAT_TEXTURED */
+#define SRT_MAT_TEXTURED 4      /* a pbr material with at least one texture slot in use */
+#define SRT_MAT_FLAGS_SHIFT 28
 
 struct DevMaterial {  // 48 B
   int32_t type;
@@ -66,6 +72,10 @@ struct DevScene {
   int32_t numNodes, numTris, numSpheres;  // record counts (buffer-resource extents)
   int32_t fastDivScene;  // 1: every box coordinate is 0 or in [2^-77, 2^30] (see fastDiv in srt_kernels.hip)
   const DevMaterial* materials;
+  // what the hit step reads: 128 bytes per material -- scalars, a light's emit texture, the four pbr texture slots
+  // resolved to (mode, width, height, texel offset); layout at srt_kernels.hip "materials"
+  const uint4* shadeRecs;
+  int32_t numMaterials;
   const DevTexture* textures;
   const uint8_t* texels;  // images of >= 3 bytes per pixel as one dword per texel (RGBA8), others as byte rows
   int32_t texelBytes;     // extent of `texels` (buffer-resource bound: reads past it return 0)

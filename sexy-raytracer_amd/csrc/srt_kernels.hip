@@ -418,7 +418,8 @@ struct Record {
   V3 p, normal, tangent, bitangent;
   float u, v, t;
   bool frontFace;
-  int material;
+  int material;  // index
+  int matType;   // SRT_MAT_* | SRT_MAT_TEXTURED: travels in the primitive's material word, so the hit step branches before it loads
   bool isTri;
 };
 
@@ -433,6 +434,8 @@ __device__ __forceinline__ void setFaceNormal(Record& rec, const Ray& r, V3 outw
 // upload); `all` forces everything (fixed-ray-set output).
 #define SRT_MAT_NEEDS_UV 1
 #define SRT_MAT_NEEDS_TANGENT 2
+// The two flags ride in the primitive's material word (bits 28-29; srt_api.cpp), so that a hit knows what to compute
+// as soon as its shading record has arrived instead of after one more dependent load.
 
 __device__ __forceinline__ void sphereRecord(const DevScene& sc, int idx, const Ray& r, float t, Record& rec, bool all) {
   const float4* sp = sc.spheres + 3 * idx;
@@ -441,9 +444,10 @@ __device__ __forceinline__ void sphereRecord(const DevScene& sc, int idx, const 
   rec.p = r.o + t * r.d;                                                  // ray.h:15-17
   V3 outward = unitv(rec.p - sphereCenter(sp, s0, s1, r.time));           // sphere.h:76
   setFaceNormal(rec, r, outward);
-  rec.material = __float_as_int(s1.w) & 0x3fffffff;
+  rec.material = __float_as_int(s1.w) & SRT_MAT_INDEX_MASK;
+  rec.matType = (__float_as_int(s1.w) >> SRT_MAT_TYPE_SHIFT) & 15;
   rec.isTri = false;
-  const int flags = all ? 3 : sc.materials[rec.material].flags;
+  const int flags = all ? 3 : (__float_as_int(s1.w) >> SRT_MAT_FLAGS_SHIFT) & 3;
   rec.u = rec.v = 0.0f;
   if (flags & SRT_MAT_NEEDS_UV) {
     float theta = acosf(-outward.y);                                      // sphere.h:32-38
@@ -466,10 +470,11 @@ __device__ __forceinline__ void triRecord(const DevScene& sc, int idx, const Ray
   const float4* sh = sc.triShade + 4 * idx;
   float4 h0 = sh[0], h1 = sh[1], h2 = sh[2], h3 = sh[3];
   V3 p = r.o + t * r.d;
-  rec.material = __float_as_int(h3.w);
+  rec.material = __float_as_int(h3.w) & SRT_MAT_INDEX_MASK;
+  rec.matType = (__float_as_int(h3.w) >> SRT_MAT_TYPE_SHIFT) & 15;
   rec.isTri = true;
   rec.u = rec.v = 0.0f;
-  if (all || (sc.materials[rec.material].flags & SRT_MAT_NEEDS_UV)) {
+  if (all || ((__float_as_int(h3.w) >> SRT_MAT_FLAGS_SHIFT) & SRT_MAT_NEEDS_UV)) {
     float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
     V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q1.x, q1.y, q1.z), v2 = mk(q2.x, q2.y, q2.z);
     // inverse-distance weights (model.h:158-169)
@@ -575,29 +580,83 @@ __device__ __forceinline__ float schlickGAF(float NdotV, float roughness) {  // 
 }
 
 // ------------------------------------------------------------------ materials
-// returns false when the path ends here (scatter == false); emitted is always set.
+// One 128-byte record per material (DevScene::shadeRecs, srt_api.cpp): the material's scalars and its texture slots
+// resolved to what a lookup needs, so that a hit issues ALL its descriptor loads at once and then ALL its texel
+// loads at once -- two round trips where material -> texture descriptor -> texel, slot after slot, made up to nine.
+//   +0   type, flags, metalness (fuzz / ir), roughness          +16  albedo
+//   +32  the emit texture of a light, in full: (mode, width | r, height | g, texel byte offset | b)
+//   +48  pbr: albedo and normal slots, two dwords each: (mode | width << 2 | height << 17, texel byte offset | id)
+//   +64  pbr: metallic and roughness slots, likewise
+// Slot modes: 0 no texture, 1 solid colour (also the magenta of a failed load; lights only), 2 image of >= 3 bytes per
+// pixel with both sides below 2^15 (one dword per texel), 3 anything else (checker, solid colour in a pbr slot, 1- and
+// 2-byte images): texValue on the texture id.
+#define SRT_SLOT_NONE 0u
+#define SRT_SLOT_SOLID 1u
+#define SRT_SLOT_IMAGE 2u
+#define SRT_SLOT_GENERIC 3u
+// byte offset of the texel an image lookup reads (imagePNG::value, texture.h:129-146)
+__device__ __forceinline__ int texelOffset(int width, int height, int base, float u, float v) {
+  u = clampf(u, 0.0f, 1.0f);
+  v = 1.0f - clampf(v, 0.0f, 1.0f);
+  int i = (int)(u * (float)width);
+  int j = (int)(v * (float)height);
+  if (!(u == u)) i = 0;  // NaN uv: UB in the reference, defined as texel 0 here and in the oracle
+  if (!(v == v)) j = 0;
+  if (i >= width) i = width - 1;
+  if (j >= height) j = height - 1;
+  return base + 4 * (j * width + i);
+}
+// a pbr slot (two dwords): where its texel is, or 0 (the load is made and ignored) when it is not an image
+__device__ __forceinline__ int slotTexelOffset(uint32_t mw, uint32_t aux, float u, float v) {
+  const int off = texelOffset((int)((mw >> 2) & 0x7fffu), (int)(mw >> 17), (int)aux, u, v);
+  return (mw & 3u) == SRT_SLOT_IMAGE ? off : 0;
+}
 template <bool COUNT>
+__device__ __forceinline__ V3 slotValue(const DevScene& sc, Rsrc rsTexels, uint32_t mw, uint32_t aux, uint32_t px, float u, float v, V3 p,
+                                        uint32_t& fetches) {
+  if ((mw & 3u) != SRT_SLOT_IMAGE) return texValue<COUNT>(sc, rsTexels, (int)aux, u, v, p, fetches);  // SRT_SLOT_GENERIC
+  if (COUNT) fetches++;
+  return mk((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu));
+}
+
+// returns false when the path ends here (scatter == false); emitted is always set.
+// WIDE: all four texel loads of a pbr hit in flight at once (the 128-register kernel); otherwise one lookup after the
+// other, which keeps four registers live instead of sixteen (the 96-register kernels spill as it is).
+template <bool COUNT, bool WIDE = false>
 __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const Ray& rIn, const Record& rec, Pcg& rng, V3& att,
                                       Ray& out, V3& emitted, uint32_t& fetches, unsigned long long* stamp = nullptr) {
-  const DevMaterial& m = sc.materials[rec.material];
+  const Rsrc rsMat = makeRsrc(sc.shadeRecs, sc.numMaterials * 128);
+  const int at = rec.material * 128;
   emitted = mk(0.0f, 0.0f, 0.0f);  // material.h:18-20
   out.o = rec.p;
   out.time = rIn.time;
-  switch (m.type) {
-    case SRT_MAT_LIGHT: {  // material.h:144-150
-      emitted = texValue<COUNT>(sc, rsTexels, m.albedoTex, rec.u, rec.v, rec.p, fetches);
-      return false;
+  if ((rec.matType & 3) == SRT_MAT_LIGHT) {  // material.h:144-150
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at + 32, 0, 0);
+    if (t.x == SRT_SLOT_IMAGE) {
+      const uint32_t px = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, texelOffset((int)t.y, (int)t.z, (int)t.w, rec.u, rec.v), 0, 0);
+      if (COUNT) fetches++;
+      emitted = mk((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu));
+    } else if (t.x == SRT_SLOT_SOLID) {
+      emitted = mk(__uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));  // texture.h:26-28
+    } else {
+      emitted = texValue<COUNT>(sc, rsTexels, (int)t.y, rec.u, rec.v, rec.p, fetches);
     }
+    return false;
+  }
+  const u32x4 head = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at, 0, 0);  // type, flags, metalness (fuzz / ir), roughness
+  const float4 albedo = bufLoad4(rsMat, at + 16);
+  const float metalness = __uint_as_float(head.z), roughness = __uint_as_float(head.w);
+  switch (rec.matType & 3) {
     case SRT_MAT_METAL: {  // material.h:91-97
       V3 reflected = reflect3(unitv(rIn.d), rec.normal);
       V3 fz = rng.inUnitSphere();  // drawn even when fuzz == 0
-      out.d = reflected + m.metalness * fz;
-      att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+      out.d = reflected + metalness * fz;
+      att = mk(albedo.x, albedo.y, albedo.z);
       return dot3(out.d, rec.normal) > 0;
     }
     case SRT_MAT_DIELECTRIC: {  // material.h:108-136
       att = mk(1.0f, 1.0f, 1.0f);
-      float ir = m.metalness;
+      float ir = metalness;
       float ratio = rec.frontFace ? (1.0f / ir) : ir;
       V3 unitDir = unitv(rIn.d);
       float cosTheta = fminf(dot3(rec.normal, -unitDir), 1.0f);  // double fmin of floats is exact
@@ -624,31 +683,37 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
       return true;
     }
     default: {  // pbrMetallicRoughness::scatter, material.h:156-245
-      V3 a0;
-      if (m.albedoTex >= 0)
-        a0 = texValue<COUNT>(sc, rsTexels, m.albedoTex, rec.u, rec.v, rec.p, fetches) / 255.0f;
-      else
-        a0 = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-      V3 normal;
-      if (m.normalTex >= 0) {
-        V3 nt = texValue<COUNT>(sc, rsTexels, m.normalTex, rec.u, rec.v, rec.p, fetches);
-        nt = mk(nt.x - 128.0f, nt.y - 128.0f, nt.z - 128.0f) / 128.0f;  // vec3.h:103-110
-        // Matrix3f(T|B|N) * nt, each row reduced x + (y + z)
-        V3 w = mk(rec.tangent.x * nt.x + (rec.bitangent.x * nt.y + rec.normal.x * nt.z),
-                  rec.tangent.y * nt.x + (rec.bitangent.y * nt.y + rec.normal.y * nt.z),
-                  rec.tangent.z * nt.x + (rec.bitangent.z * nt.y + rec.normal.z * nt.z));
-        normal = unitv(w);
-      } else
-        normal = rec.normal;
-      float mt, rg;
-      if (m.metallicTex >= 0)
-        mt = clampf(texValue<COUNT>(sc, rsTexels, m.metallicTex, rec.u, rec.v, rec.p, fetches).x / 255.0f, 0.0f, 1.0f);
-      else
-        mt = m.metalness;
-      if (m.roughnessTex >= 0)
-        rg = clampf(texValue<COUNT>(sc, rsTexels, m.roughnessTex, rec.u, rec.v, rec.p, fetches).y / 255.0f, 0.0f, 1.0f);
-      else
-        rg = m.roughness;
+      V3 a0 = mk(albedo.x, albedo.y, albedo.z), normal = rec.normal;
+      float mt = metalness, rg = roughness;
+      if (rec.matType & SRT_MAT_TEXTURED) {  // some texture slot is in use: skipped by waves whose hits have none
+        const u32x4 tAN = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at + 48, 0, 0), tMR = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at + 64, 0, 0);
+        // WIDE: the four texel loads go out together (an absent or non-image slot reads texel 0 of the buffer and
+        // ignores it); otherwise each is made where its value is used
+        uint32_t pA = 0, pN = 0, pM = 0, pR = 0;
+        if (WIDE) {
+          pA = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tAN.x, tAN.y, rec.u, rec.v), 0, 0);
+          pN = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tAN.z, tAN.w, rec.u, rec.v), 0, 0);
+          pM = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tMR.x, tMR.y, rec.u, rec.v), 0, 0);
+          pR = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tMR.z, tMR.w, rec.u, rec.v), 0, 0);
+        }
+        auto fetch = [&](uint32_t mw, uint32_t aux, uint32_t early) {
+          return WIDE || (mw & 3u) != SRT_SLOT_IMAGE ? early : __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(mw, aux, rec.u, rec.v), 0, 0);
+        };
+        if ((tAN.x & 3u) != SRT_SLOT_NONE) a0 = slotValue<COUNT>(sc, rsTexels, tAN.x, tAN.y, fetch(tAN.x, tAN.y, pA), rec.u, rec.v, rec.p, fetches) / 255.0f;
+        if ((tAN.z & 3u) != SRT_SLOT_NONE) {
+          V3 nt = slotValue<COUNT>(sc, rsTexels, tAN.z, tAN.w, fetch(tAN.z, tAN.w, pN), rec.u, rec.v, rec.p, fetches);
+          nt = mk(nt.x - 128.0f, nt.y - 128.0f, nt.z - 128.0f) / 128.0f;  // vec3.h:103-110
+          // Matrix3f(T|B|N) * nt, each row reduced x + (y + z)
+          V3 w = mk(rec.tangent.x * nt.x + (rec.bitangent.x * nt.y + rec.normal.x * nt.z),
+                    rec.tangent.y * nt.x + (rec.bitangent.y * nt.y + rec.normal.y * nt.z),
+                    rec.tangent.z * nt.x + (rec.bitangent.z * nt.y + rec.normal.z * nt.z));
+          normal = unitv(w);
+        }
+        if ((tMR.x & 3u) != SRT_SLOT_NONE)
+          mt = clampf(slotValue<COUNT>(sc, rsTexels, tMR.x, tMR.y, fetch(tMR.x, tMR.y, pM), rec.u, rec.v, rec.p, fetches).x / 255.0f, 0.0f, 1.0f);
+        if ((tMR.z & 3u) != SRT_SLOT_NONE)
+          rg = clampf(slotValue<COUNT>(sc, rsTexels, tMR.z, tMR.w, fetch(tMR.z, tMR.w, pR), rec.u, rec.v, rec.p, fetches).y / 255.0f, 0.0f, 1.0f);
+      }
 
       if (COUNT && stamp) stamp[0] = clock64();  // textures done
       V3 sd = normal + unitv(rng.inUnitSphere());  // randomUnitVector, vec3.h:72-74
@@ -663,7 +728,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
       float NdotH = fmaxf(dot3(normal, halfVec), 0.0f);
       float HdotV = fmaxf(dot3(halfVec, viewVec), 0.0f);
       float NdotV = fmaxf(dot3(normal, viewVec), 0.0f);
-      V3 fr = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+      V3 fr = mk(albedo.x, albedo.y, albedo.z);
       // lerp(0.4, fr, mt), vec3.h:97-101.  F0 for dielectrics is 0.4 (material.h:228)
       V3 F0 = mk((1.0f - mt) * 0.4f + mt * fr.x, (1.0f - mt) * 0.4f + mt * fr.y, (1.0f - mt) * 0.4f + mt * fr.z);
       float D = trowbridgeReitzNDF(NdotH, rg);
@@ -674,7 +739,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
       V3 fd = a0 / SRT_PI;
       fd = mk(fd.x * (1.0f - F.x), fd.y * (1.0f - F.y), fd.z * (1.0f - F.z));
       fd = fd * (1.0f - mt);
-      fd = mk(fd.x * m.albedo[0], fd.y * m.albedo[1], fd.z * m.albedo[2]);
+      fd = mk(fd.x * albedo.x, fd.y * albedo.y, fd.z * albedo.z);
       V3 fs = ((D * F) * G) / (4.0f * NdotV * NdotL + SRT_EPS);
       att = (fd + fs) * NdotL;
       return true;
@@ -1144,7 +1209,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
         uint32_t fetches = 0;
         if (COUNT && rec.isTri) cShTri++;
         if (COUNT) h1 = clock64();
-        bool scattered = shade<COUNT>(sc, rsTexels, ray, rec, rng, att, next, emitted, fetches, COUNT ? hStamp : nullptr);
+        bool scattered = shade<COUNT, LDSTREE>(sc, rsTexels, ray, rec, rng, att, next, emitted, fetches, COUNT ? hStamp : nullptr);
         if (COUNT) cTex += fetches;
         V3 terminal = emitted;  // main.cpp:46-47
         bool done = true;
@@ -1469,6 +1534,7 @@ __global__ void srt_scatter_kernel(const ScatterArgs a) {
   Record rec;
   rec.p = ld3(h.p); rec.normal = ld3(h.normal); rec.tangent = ld3(h.tangent); rec.bitangent = ld3(h.bitangent);
   rec.u = h.uv[0]; rec.v = h.uv[1]; rec.t = h.t; rec.frontFace = h.frontFace != 0; rec.material = h.material;
+  rec.matType = (int)a.scene.shadeRecs[8 * h.material].x;  // a caller-made hit record has no material word: type | SRT_MAT_TEXTURED from the record
   rec.isTri = false;
   Pcg rng;
   rng.key(mix64(a.seed), (uint32_t)i, 0u);

@@ -547,7 +547,7 @@ def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camer
     import torch
     W, H = 320, 180
     default = ctx.get_tunable("lds_tree")
-    assert default > 1  # a node count: smaller trees stay with the 256-thread kernel
+    assert default >= 1  # a node-count threshold; 1 = every tree that fits
     for name, spp, mb in (("masterchief", 8, 4), ("spheres", 8, 8), ("iron", 4, 4)):
         ctx.upload_scene(srt.scenes.SCENES[name]())
         ctx.set_camera(camera)

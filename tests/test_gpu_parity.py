@@ -208,6 +208,25 @@ def test_render_240p_vs_oracle(ctx, oracle, abi, scenes, camera, name, spp, mb, 
         assert_counter(st[k], want_st[k], k)
 
 
+def test_render_720p_headline_frame_vs_oracle(ctx, oracle, abi, scenes, camera, node_path):
+    """The headline frame at its BASELINE size (1280x720, 4 bounces) through the PRODUCTION (non-counting) render
+    kernel, 8 of its samples per pixel, against the oracle with identical counter-RNG keys: the chunked default
+    (exact chunk sums) and the reference's single running sum."""
+    sb = scenes["masterchief"]
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    osc = oracle.OracleScene(sb)
+    for chunks in (1, 0):
+        p = abi.default_render_params(1280, 720, 8, 4, seed=7, spp_chunks=chunks)
+        acc, rgba = ctx.render_image(p)
+        if chunks == 1:
+            want_acc, want_rgba, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=min(16, os.cpu_count() or 8), want_stats=False)
+        # one running sum: bit-identical; exact chunk sums: the same samples added in another association (<= 2e-5 relative)
+        assert_accum_close(acc, want_acc, min_bitexact=0.999 if chunks == 1 else 0.0)
+        assert_rgba_close(rgba, want_rgba)
+    assert ctx.launch_info()["lds_tree"] == bool(node_path)
+
+
 def test_sphere_field_vs_oracle(ctx, oracle, abi, srt, camera, node_path):
     """the 22x22 sphere field main.cpp:92-122 keeps commented out -- 480-odd small spheres,
     most of them moving (sphere.h:47-52), fuzzy metals and glass, in one bvhNode: same tree as the oracle,

@@ -20,6 +20,11 @@
 //     (E + A*(E' + A'*(...))) exactly.
 //   * BVH traversal is a per-lane DFS in the reference's fixed left-then-right order with the pending
 //     right children on a per-lane LDS stack laid out [slot][thread] (bank = thread: conflict-free).
+//   * a scene whose whole node array fits a CU's 160 KB of LDS is traversed OUT OF LDS: one workgroup of 1024
+//     threads per CU copies the node records in and keeps 16-bit stacks behind them (LDSTREE, see the kernel);
+//     larger scenes read the records through the vector L1 with 256-thread workgroups.
+//   * a hit reads ONE flattened record per material (scalars + texture slots resolved at upload), its type and
+//     flags travel in the primitive's material word: two round trips to memory per shaded hit (shade).
 //   * RNG: PCG32 keyed by (seed, pixel, sample) per lane.
 //   * all arithmetic keeps the reference's operation order; built with -ffp-contract=off; divisions and
 //     sqrt are IEEE (hipcc default); the slab test is decided from one FMA per plane under an error

@@ -326,7 +326,7 @@ const TunableName kTunables[] = {
     {"fast_div", "SRT_FAST_DIV", &Tunables::fastDiv, 1},
     {"prim_again_min", "SRT_PRIM_AGAIN_MIN", &Tunables::primAgainMin, 4},
     {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
-    {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 2560},  // budget of the chunk-slot path
+    {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 12288},  // budget of the chunk-slot path
     {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 1},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
 };
 
@@ -941,19 +941,20 @@ int32_t srtNumLocalTiles(int32_t w, int32_t h, int32_t stride) {
   return (srtNumTiles(w, h) + stride - 1) / stride;
 }
 
-// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about 32 samples per
-// item, at least 128 items per pixel when there are that many samples (down to one sample per item), at most 160.
+// Work items per pixel when the caller leaves the choice to the library (sppChunks == 0): about 8 samples per
+// item, at least 128 items per pixel when there are that many samples (down to one sample per item), at most 640.
 // It depends on the sample count alone, so that the chunk boundaries -- and with them the image, bit for bit --
 // are the same for every tile split and GPU count.  Many items per pixel keep the tiles in flight few (a queue's
-// waves pull consecutive items, i.e. the chunks of one tile, then of its neighbour) and that coherence is worth
-// more than the cost of small items; a small share of a frame needs it most.  Round 2, 720p headline at 5000 spp
-// (profiles/r02/chunk_policy.txt): whole frame 1 chunk 500, 4: 2274, 16: 2983, 32: 3195, 64: 3395, 157: 3393,
-// 256: 3362, 1024: 3178 Msamples/s; one of 8 ranks' share 219 / 186 / 184 ms with 64 / 157 / 256 chunks
-// (169 ms would be an eighth of the frame).  Low sample counts: 64 spp on the 240p spheres frame run at
-// 5.9 / 6.4 / 7.1 Gsamples/s with 16 / 32 / 64 chunks.
+// waves pull consecutive items, i.e. the chunks of one tile, then of its neighbour), and SMALL items keep the end
+// of a launch short: the last items to finish are single pixels of the mesh, ten times the average pixel's cost,
+// and a rank's share of a frame feels that tail most.  720p headline at 5000 spp on the LDS-resident-tree kernel
+// (profiles/r02/chunk_policy.txt): whole frame 1069.9 / 1067.9 / 1066.7 / 1068.1 ms with 157 / 314 / 628 / 1250
+// chunks (as long as the chunk slots fit the scratch budget; the atomic path costs 1.2 %); one of 8 ranks' share
+// 148.5 / 142.5 / 139.5 / 138.3 ms (133.7 would be an eighth of the frame).  Low sample counts: 64 spp on the 240p
+// spheres frame run at 4.3 / 5.2 / 6.2 / 7.1 / 7.8 Gsamples/s with 4 / 8 / 16 / 32 / 64 chunks.
 int32_t srtDefaultSppChunks(int32_t spp) {
-  const int32_t bySize = (spp + 31) / 32, byCount = std::min(128, spp);
-  return std::max(1, std::min(160, std::max(bySize, byCount)));
+  const int32_t bySize = (spp + 7) / 8, byCount = std::min(128, spp);
+  return std::max(1, std::min(640, std::max(bySize, byCount)));
 }
 
 static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
@@ -1014,7 +1015,8 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   {
     // work items and output slots are indexed with 32-bit integers in the kernel (queue counters run over
     // whole units, so count the padding of the last unit of every queue too)
-    const int64_t perChunk = ((int64_t)a.numLocalTiles + (int64_t)a.unitTiles * a.numQueues) * SRT_TILE_PIXELS;
+    // (the whole image's tile count, not this rank's: the clamp must not depend on the tile split)
+    const int64_t perChunk = ((int64_t)a.numTiles + (int64_t)1024 * SRT_MAX_QUEUES) * SRT_TILE_PIXELS;  // 1024 = the largest unit
     const int64_t maxChunks = (int64_t)0x7fffffff / std::max<int64_t>(perChunk, 1);
     if (maxChunks < 1) return fail(ctx, "render: image too large (%d local tiles)", a.numLocalTiles);
     if (a.sppChunks > maxChunks) {

@@ -147,9 +147,9 @@ def test_no_gpu_is_an_error_not_a_fallback(dev):
 
 
 def test_default_chunk_plan(dev):
-    """srtDefaultSppChunks: ~32 samples per item, at least 128 items per pixel when there are that many
-    samples, never more chunks than samples, at most 160 (srt_api.cpp); a function of the sample count alone."""
-    want = {1: 1, 2: 2, 16: 16, 64: 64, 100: 100, 128: 128, 333: 128, 1000: 128, 4096: 128, 5000: 157, 8192: 160, 10 ** 6: 160}
+    """srtDefaultSppChunks: ~8 samples per item, at least 128 items per pixel when there are that many
+    samples, never more chunks than samples, at most 640 (srt_api.cpp); a function of the sample count alone."""
+    want = {1: 1, 2: 2, 16: 16, 64: 64, 100: 100, 128: 128, 333: 128, 1000: 128, 1024: 128, 4096: 512, 5000: 625, 8192: 640, 10 ** 6: 640}
     for spp, chunks in want.items():
         assert dev.default_spp_chunks(spp) == chunks, spp
         assert 1 <= dev.default_spp_chunks(spp) <= spp

@@ -205,8 +205,9 @@ class SceneBuilder:
                                             metallicTex=-1, roughnessTex=-1, ir=ir))
         return len(self.materials) - 1
 
-    def light(self, color):
-        t = self.solid(*color)
+    def light(self, color=None, emit_tex=None):
+        """diffuseLight (material.h:138-150): a colour, or any texture id as the emit texture."""
+        t = self.solid(*color) if emit_tex is None else emit_tex
         self.materials.append(SrtMaterialIn(type=SRT_MAT_LIGHT, albedoTex=t, normalTex=-1,
                                             metallicTex=-1, roughnessTex=-1))
         return len(self.materials) - 1

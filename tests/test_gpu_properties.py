@@ -213,10 +213,23 @@ def _world_variants(abi):
     sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=sb.checker((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))
     sb.world_bvh(0, None, 0.0, 1.0)
     out["textures"] = sb
+    # the ways a shading record's slots can be filled (srt_kernels.hip "materials") beyond the variants above: lights
+    # emitting an image and a checker, a 4-byte image in all four pbr slots, an image wider than a packed slot takes
+    sb = abi.SceneBuilder()
+    rgba = sb.image((np.arange(9 * 5 * 4, dtype=np.uint8).reshape(5, 9, 4) * 5 + 11), 4)
+    rgb = sb.image((np.arange(6 * 4 * 3, dtype=np.uint8).reshape(4, 6, 3) * 3 + 40), 3)
+    wide = sb.image(np.tile(np.arange(40000, dtype=np.uint32)[None, :, None] % 251, (1, 1, 3)).astype(np.uint8), 3)  # 40000 x 1
+    sb.add_sphere((-3.0, 2.5, 0.5), 0.8, sb.light(emit_tex=rgba))
+    sb.add_sphere((3.2, 3.0, -0.5), 0.6, sb.light(emit_tex=sb.checker((3.0, 0.5, 0.5), (0.5, 0.5, 3.0))))
+    sb.add_sphere((0.0, 1.5, 0.0), 1.5, sb.pbr(albedo_tex=rgba, normal_tex=rgba, metallic_tex=rgba, roughness_tex=rgba))
+    sb.add_sphere((2.5, 1.0, 1.5), 1.0, sb.pbr(albedo_tex=wide, roughness_tex=rgb, metalness=0.2))
+    sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo_tex=rgb, roughness=0.7))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    out["slots"] = sb
     return out
 
 
-@pytest.mark.parametrize("variant", ["list", "two_bvh", "moving", "textures"])
+@pytest.mark.parametrize("variant", ["list", "two_bvh", "moving", "textures", "slots"])
 def test_world_and_material_variants_vs_oracle(ctx, oracle, abi, camera, variant, node_path):
     sb = _world_variants(abi)[variant]
     ctx.upload_scene(sb)

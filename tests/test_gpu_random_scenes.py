@@ -57,7 +57,7 @@ def random_scene(abi, seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_scene_trace_and_render(ctx, oracle, abi, camera, seed):
+def test_random_scene_trace_and_render(ctx, oracle, abi, camera, seed, node_path):
     sb = random_scene(abi, 1000 + seed)
     ctx.upload_scene(sb)
     ctx.set_camera(camera)

@@ -453,7 +453,7 @@ def main():
         elif rank == 0:
             gathered_buf = torch.empty((world, nloc, 64, 4), dtype=torch.float32, device="cuda")
 
-    launch = {"lds_tree": False, "workgroups": 0, "threads": 0, "lds_bytes": 0}
+    launch = {"lds_tree": False, "lds_tree_mode": 0, "workgroups": 0, "threads": 0, "lds_bytes": 0}
 
     def step(record):
         ctx.render_tiles(params, local.data_ptr(), stream)
@@ -516,8 +516,9 @@ def main():
             pmc["_samples"] = samples_per_launch
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        kernel_name = "srt_render_kernel<%s,false,true,%s>" % ("true" if traversal == "closest" else "false",
-                                                               "true" if launch["lds_tree"] else "false")
+        kernel_name = "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
+                                                                  "true" if launch["lds_tree"] else "false",
+                                                                  "true" if launch.get("lds_tree_mode") == 2 else "false")
         line = {
             "metric": "Msamples/s (WxHxspp/s), 720p masterchief @5k spp" if args.workload == "masterchief_720p_5000spp"
                       else "Msamples/s (WxHxspp/s), " + args.workload,
@@ -533,7 +534,8 @@ def main():
                                                                                      + (" (native communicator unavailable)" if native_note else "")))},
             "device": info,
             "launch": {"workgroups": launch["workgroups"], "threads_per_workgroup": launch["threads"], "lds_bytes_per_workgroup": launch["lds_bytes"],
-                       "node_records": "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM"},
+                       "node_records": "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM",
+                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") == 1 else "LDS"},
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),
         }

@@ -41,9 +41,9 @@ int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAo
  *           hit-step executions, hit-step lanes, restart-step executions, restart-step lanes, reserved }. */
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10);
 
-/* The most recent render-kernel launch: out4 = { 1 if the LDS-resident-tree variant ran (FAITHFUL, node array small
- * enough for a CU's LDS; tunable "lds_tree" = 0 switches it off), workgroups, threads per workgroup, LDS bytes per
- * workgroup }. */
+/* The most recent render-kernel launch: out4 = { 0 node records through the L1, 1 the LDS-resident-tree variant
+ * (FAITHFUL, node array small enough for a CU's LDS; tunable "lds_tree" = 0 switches it off), 2 the same with the
+ * attenuation stacks in LDS as well; workgroups; threads per workgroup; LDS bytes per workgroup }. */
 int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4);
 
 /* Per-context diagnostic tunables of the work distribution and the wave scheduler ("queues", "unit_tiles",

@@ -1100,15 +1100,19 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   // texel loads in flight together where the 96-register one spills, profiles/r02/lds_tree.txt.)
   const bool ldsTree = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->tun.ldsTree > 0 && ctx->scene.numNodes >= ctx->tun.ldsTree && ldsTreeBytes <= 160 * 1024 &&
                        ctx->scene.numNodes < 32767 && 2 * (int64_t)ctx->scene.numTris < 32766 && 2 * (int64_t)ctx->scene.numSpheres + 1 < 32766;
-  const size_t lds = ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);
+  // ... and when the attenuation stacks fit behind them as well they stay in LDS (ldsTreeMode 2): +2 to +5 % on the
+  // small BASELINE scenes; the headline scene's tree leaves no room (mode 1: they live in global memory)
+  const size_t attBytes = (size_t)(3 * p->maxBounce + 3) * 1024 * sizeof(float);
+  const int ldsTreeMode = !ldsTree ? 0 : (ldsTreeBytes + attBytes <= 160 * 1024 ? 2 : 1);
+  const size_t lds = ldsTreeMode == 2 ? ldsTreeBytes + attBytes : ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   int perCU = 0;
-  if (srt_render_occupancy(p->traversal, p->countStats, ldsTree, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  if (srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
   const int wgWaves = ldsTree ? 16 : 4;
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * wgWaves - 1) / (SRT_TILE_PIXELS * wgWaves));
   if (grid < 1) grid = 1;
-  if (ldsTree) {
+  if (ldsTreeMode == 1) {
     const size_t need = (size_t)(3 * p->maxBounce + 3) * grid * 1024 * sizeof(float);
     if (ctx->attScratch.bytes < need) {
       if (ctx->attScratch.p) HIP_OK(ctx, hipFree(ctx->attScratch.p));
@@ -1121,11 +1125,11 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  ctx->lastLaunch[0] = ldsTree ? 1 : 0;
+  ctx->lastLaunch[0] = ldsTreeMode;
   ctx->lastLaunch[1] = grid;
   ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
   ctx->lastLaunch[3] = (int32_t)lds;
-  int rc = srt_launch_render(&a, p->traversal, p->countStats, ldsTree, grid, lds, stream);
+  int rc = srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;

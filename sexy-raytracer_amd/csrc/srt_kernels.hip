@@ -847,9 +847,11 @@ enum { M_NODE = 0, M_PRIM = 1, M_SHADE = 2, M_EXIT = 3, M_HIT = 4 };
 // traversal stack holds 16-bit references (node INDEX or primitive reference; the node records are rewritten
 // to indices while they are copied in, so a visit's address is cur << 5) and the attenuation stack moves to
 // global memory (three coalesced stores per bounce).  Same records, same arithmetic, same decisions.
-template <bool CLOSEST, bool COUNT, bool SINGLE, bool LDSTREE>
+// ATTLDS (with LDSTREE): the tree is small enough to leave the attenuation stacks in LDS too.
+template <bool CLOSEST, bool COUNT, bool SINGLE, bool LDSTREE, bool ATTLDS>
 __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT_TREE_WAVES_PER_SIMD : SRT_RENDER_WAVES_PER_SIMD) void srt_render_kernel(
     const RenderArgs a) {
+  static_assert(LDSTREE || !ATTLDS, "ATTLDS qualifies the LDS-resident-tree kernel");
   static_assert(!(CLOSEST && LDSTREE), "the LDS-resident tree serves the FAITHFUL traversal");
   constexpr int BLOCK = LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK;  // threads per workgroup = stride of the [slot][thread] arrays
   // "no reference": what popping the empty stack yields.  LDSTREE: the 16-bit sentinel, sign-extended.
@@ -863,9 +865,12 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
   const int treeBytes = LDSTREE ? a.scene.numNodes * 32 : 0;
   StackT* const stackBase = reinterpret_cast<StackT*>(ldsTree + treeBytes) + threadIdx.x;
   *stackBase = (StackT)DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
-  float* attStack = LDSTREE ? a.attScratch + (size_t)blockIdx.x * BLOCK + threadIdx.x
-                            : reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * BLOCK + threadIdx.x);
-  const int attStride = LDSTREE ? (int)gridDim.x * BLOCK : BLOCK;
+  // attenuation slots: behind the traversal slots (256-thread kernel), behind the 16 queue words (LDSTREE with room,
+  // ATTLDS), or in global memory (LDSTREE with a tree that leaves no room)
+  float* attStack = !LDSTREE ? reinterpret_cast<float*>(lds + (a.scene.stackDepth + 2) * BLOCK + threadIdx.x)
+                    : ATTLDS ? reinterpret_cast<float*>(ldsTree + treeBytes + (a.scene.stackDepth + 2) * BLOCK * (int)sizeof(StackT) + 64) + threadIdx.x
+                             : a.attScratch + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int attStride = LDSTREE && !ATTLDS ? (int)gridDim.x * BLOCK : BLOCK;
   const int lane = threadIdx.x & 63;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
@@ -1561,19 +1566,25 @@ extern "C" {
 
 namespace {
 typedef void (*RenderKernel)(const RenderArgs);
+// ldsTree: 0 = node records through the L1 (256 threads), 1 = LDS-resident tree (FAITHFUL, 1024 threads, attenuation
+// stacks in global memory), 2 = the same with the attenuation stacks in LDS too
 RenderKernel renderVariant(const RenderArgs* a, int traversal, int count, int ldsTree) {
   const bool closest = traversal == SRT_TRAVERSE_CLOSEST, single = a == nullptr || a->scene.numWorld == 1;
-  if (ldsTree && !closest) {
-    if (count) return srt_render_kernel<false, true, false, true>;
-    return single ? srt_render_kernel<false, false, true, true> : srt_render_kernel<false, false, false, true>;
+  if (ldsTree == 2 && !closest) {
+    if (count) return srt_render_kernel<false, true, false, true, true>;
+    return single ? srt_render_kernel<false, false, true, true, true> : srt_render_kernel<false, false, false, true, true>;
   }
-  if (count) return closest ? srt_render_kernel<true, true, false, false> : srt_render_kernel<false, true, false, false>;
-  if (single) return closest ? srt_render_kernel<true, false, true, false> : srt_render_kernel<false, false, true, false>;
-  return closest ? srt_render_kernel<true, false, false, false> : srt_render_kernel<false, false, false, false>;
+  if (ldsTree && !closest) {
+    if (count) return srt_render_kernel<false, true, false, true, false>;
+    return single ? srt_render_kernel<false, false, true, true, false> : srt_render_kernel<false, false, false, true, false>;
+  }
+  if (count) return closest ? srt_render_kernel<true, true, false, false, false> : srt_render_kernel<false, true, false, false, false>;
+  if (single) return closest ? srt_render_kernel<true, false, true, false, false> : srt_render_kernel<false, false, true, false, false>;
+  return closest ? srt_render_kernel<true, false, false, false, false> : srt_render_kernel<false, false, false, false, false>;
 }
 }  // namespace
 
-// ldsTree: the LDS-resident-tree variant (FAITHFUL): workgroups of SRT_BLOCK_TREE threads, up to 160 KB of LDS each
+// ldsTree != 0: an LDS-resident-tree variant (FAITHFUL): workgroups of SRT_BLOCK_TREE threads, up to 160 KB of LDS each
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream) {
   const RenderKernel k = renderVariant(a, traversal, count, ldsTree);
   if (ldsBytes > 64 * 1024) {

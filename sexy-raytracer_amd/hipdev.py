@@ -262,7 +262,7 @@ class Context:
         """The most recent render launch: {"lds_tree", "workgroups", "threads", "lds_bytes"} (include/srt_hip_test.h)."""
         out = np.zeros(4, np.int32)
         self._check(lib.srtGetLaunchInfo(self.h, out.ctypes.data))
-        return {"lds_tree": bool(out[0]), "workgroups": int(out[1]), "threads": int(out[2]), "lds_bytes": int(out[3])}
+        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "workgroups": int(out[1]), "threads": int(out[2]), "lds_bytes": int(out[3])}
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -574,6 +574,8 @@ def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camer
                 torch.cuda.synchronize()
                 info = ctx.launch_info()
                 assert info["lds_tree"] == bool(tree), (name, tree, info)
+                # the headline mesh's tree leaves no room for the attenuation stacks (mode 1), the small trees do (mode 2)
+                assert info["lds_tree_mode"] == (0 if not tree else 1 if name == "masterchief" else 2), (name, info)
                 assert info["threads"] == (1024 if tree else 256)
                 assert info["lds_bytes"] <= 160 * 1024
                 images[tree] = local.cpu().numpy()

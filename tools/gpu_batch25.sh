@@ -2,7 +2,7 @@
 # round-2 final measurement set (after the LDS-resident tree and the flattened shading records): parity suite, the driver's default bench run, rocprofv3 kernel stats, counters of every
 # workload, partition balance
 set -o pipefail
-O=gpurun_out/r3e; mkdir -p $O
+O=gpurun_out/r3f; mkdir -p $O
 timeout -k 10 600 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.txt; grep -a "passed\|failed\|Error\|^E  " $O/pytest.txt | tail -12
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout -k 10 900 python bench.py --save-pmc > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?"; python -c "import json;d=json.load(open('$O/bench_default.json'));r=d['roofline'];print(d['value'], r['kernel_ms_avg'], 'frac', r.get('frac'), 'issue', r.get('issue_frac'), 'lanes', r.get('lane_utilisation'), 'valu/sample', r.get('valu_wave_instr_per_sample'), 'traffic', r.get('traffic'), d['config']['spp_chunks'])"

@@ -1,7 +1,11 @@
 // Builds a scene through the C++ host layer and dumps its flattened form (no GPU needed):
 // used by tests/test_host_cpp.py to compare the C++ scene-build path with the Python one.
 //   srt_flatten_dump <gltf> <out.bin> [png-roundtrip.png]
+//   srt_flatten_dump --model <gltf|glb>      what gltfLoad made of the file: one line per mesh (vertex, texcoord,
+//                                            triangle counts, material factors, FNV-1a of the raw arrays) and one for
+//                                            the triangles as objects.add() would see them (main.cpp:81-85)
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 
 #include "srt/bvh.h"
@@ -17,8 +21,49 @@ static void put(FILE* f, const std::vector<T>& v) {
   if (n) fwrite(v.data(), sizeof(T), v.size(), f);
 }
 
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+
+static int dumpModel(const char* path) {
+  auto m = model::create(path);
+  if (!m->init()) {
+    std::cout << "gltfLoad failed\n";
+    return 1;
+  }
+  sceneFlattener f;
+  for (size_t i = 0; i < m->meshes.size(); ++i) {
+    const auto& ms = m->meshes[i];
+    uint64_t hp = 1469598103934665603ull, ht = hp;
+    for (const auto& p : ms->positions) {
+      float v[3] = {p(0), p(1), p(2)};
+      hp = fnv(v, 12, hp);
+    }
+    for (const auto& t : ms->texcoords) {
+      float v[2] = {t(0), t(1)};
+      ht = fnv(v, 8, ht);
+    }
+    std::cout << "mesh " << i << " positions " << ms->positions.size() << " texcoords " << ms->texcoords.size() << " triangles "
+              << ms->triangles.size() << " material " << (ms->matPtr ? 1 : 0) << " hp " << hp << " ht " << ht << "\n";
+    if (ms->matPtr || ms->triangles.empty())
+      for (const auto& t : ms->triangles) t->populate(f);
+  }
+  uint64_t h = 1469598103934665603ull;
+  for (const auto& t : f.triangles) h = fnv(t.uv, sizeof(t.uv), fnv(t.p, sizeof(t.p), h));
+  std::cout << "flattened triangles " << f.triangles.size() << " materials " << f.materials.size() << " textures " << f.textures.size()
+            << " hash " << h << "\n";
+  for (const auto& mt : f.materials)
+    std::cout << "material type " << mt.type << " albedo " << mt.albedo[0] << " " << mt.albedo[1] << " " << mt.albedo[2] << " " << mt.albedo[3]
+              << " metalness " << mt.metalness << " roughness " << mt.roughness << " albedoTex " << mt.albedoTex << " normalTex " << mt.normalTex << "\n";
+  for (const auto& t : f.textures) std::cout << "texture kind " << t.kind << " " << t.width << "x" << t.height << " bpp " << t.bpp << "\n";
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
+  if (!strcmp(argv[1], "--model")) return dumpModel(argv[2]);
   srtHostRandomReset();
   hittableList objects, scene;
   auto m = model::create(argv[1]);

@@ -1143,11 +1143,6 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
             }
             const int axis = CLOSEST ? sc.nodeAxis[cur >> 5] : 3;  // issued with the node record, used after the box test
             const int top = *sptr;  // pending reference, or the sentinel: read while the node record is on its way
-#if defined(SRT_PROBE_LOAD128)
-            const u32x4 probe = __builtin_amdgcn_raw_buffer_load_b128(rsNodes, cur + 32, 0, 0);  // timing probe: one more 16-B load
-#elif defined(SRT_PROBE_LOAD32)
-            const uint32_t probe = __builtin_amdgcn_raw_buffer_load_b32(rsNodes, cur + 32, 0, 0);  // timing probe: one more 4-B load
-#endif
             if (COUNT) cNodes++;
             // certified one-FMA test for every lane; the few visits it cannot decide, and every visit of a ray
             // outside fastDiv's operand ranges (slabTol = inf), take the IEEE divisions
@@ -1173,18 +1168,6 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
             // spare) is the tree's maximum number of pending references, computed or verified at upload.
             int move = hitBox ? (right != left ? 1 : 0) : -1;  // slots; selects of inline constants
             asm("" : "+v"(move));  // keep it in slots: folded into bytes it needs two literal moves per visit
-#if defined(SRT_PROBE_LOAD128)
-            if (probe.x == 0x7fc12345u) move = 0;  // never true for a box coordinate; keeps the probe load alive
-#elif defined(SRT_PROBE_LOAD32)
-            if (probe == 0x7fc12345u) move = 0;
-#elif defined(SRT_PROBE_VALU)
-            {  // timing probe: eight dependent VALU instructions more per visit
-              float pv = closest;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pv));
-              if (__float_as_uint(pv) == 0x7fc12345u) move = 0;
-            }
-#endif
             sptr += move * BLOCK;  // one shift-add
             cur = hitBox ? left : top;
             if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list

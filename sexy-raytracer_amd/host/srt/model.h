@@ -125,29 +125,127 @@ inline std::string srtDataDir() {
   return d;
 }
 
+// ---- what cgltf_parse_file + cgltf_load_buffers accept (model.h:301-315, cgltf file type 0 = detect) ----
+// base64 as cgltf_load_buffer_base64 reads it: exactly `size` bytes are decoded (the '=' padding is never
+// reached); a character outside the alphabet before that is an error.
+inline bool srtBase64Decode(const char* src, size_t srcLen, size_t size, std::vector<uint8_t>& out) {
+  out.clear();
+  out.reserve(size);
+  unsigned buffer = 0, bits = 0;
+  size_t at = 0;
+  for (size_t i = 0; i < size; ++i) {
+    while (bits < 8) {
+      if (at >= srcLen) return false;
+      const char ch = src[at++];
+      int index = (unsigned)(ch - 'A') < 26   ? (ch - 'A')
+                  : (unsigned)(ch - 'a') < 26 ? (ch - 'a') + 26
+                  : (unsigned)(ch - '0') < 10 ? (ch - '0') + 52
+                  : ch == '+'                 ? 62
+                  : ch == '/'                 ? 63
+                                              : -1;
+      if (index < 0) return false;
+      buffer = (buffer << 6) | (unsigned)index;
+      bits += 6;
+    }
+    out.push_back((uint8_t)(buffer >> (bits - 8)));
+    bits -= 8;
+  }
+  return true;
+}
+// %XX escapes of a relative file URI (cgltf_decode_uri)
+inline std::string srtUriDecode(const std::string& uri) {
+  auto hex = [](char c) { return (unsigned)(c - '0') < 10 ? c - '0' : (unsigned)((c | 32) - 'a') < 6 ? (c | 32) - 'a' + 10 : -1; };
+  std::string out;
+  for (size_t i = 0; i < uri.size(); ++i) {
+    if (uri[i] == '%' && i + 2 < uri.size() && hex(uri[i + 1]) >= 0 && hex(uri[i + 2]) >= 0) {
+      out.push_back((char)(hex(uri[i + 1]) * 16 + hex(uri[i + 2])));
+      i += 2;
+    } else {
+      out.push_back(uri[i]);
+    }
+  }
+  return out;
+}
+// The JSON text and, for a binary .glb (magic "glTF", version 2: 12-byte header, JSON chunk, optional BIN chunk),
+// the BIN chunk.  Returns false for what cgltf_parse rejects (short file, wrong version, wrong chunk magic).
+inline bool srtGltfSplit(const std::string& file, std::string& json, std::vector<uint8_t>& bin, bool& hasBin) {
+  hasBin = false;
+  auto u32 = [&](size_t at) {
+    uint32_t v;
+    memcpy(&v, file.data() + at, 4);
+    return v;
+  };
+  if (file.size() < 4 || u32(0) != 0x46546C67u) {  // not "glTF": JSON text
+    json = file;
+    return !file.empty();
+  }
+  if (file.size() < 20 || u32(4) != 2u || u32(8) > file.size()) return false;
+  const size_t total = u32(8), jsonLen = u32(12);
+  if (u32(16) != 0x4E4F534Au || 20 + jsonLen > total) return false;  // "JSON"
+  json.assign(file, 20, jsonLen);
+  const size_t binHdr = 20 + jsonLen;
+  if (binHdr + 8 <= total) {
+    const size_t binLen = u32(binHdr);
+    if (u32(binHdr + 4) != 0x004E4942u || binHdr + 8 + binLen > total) return false;  // "BIN\0"
+    bin.assign(file.begin() + binHdr + 8, file.begin() + binHdr + 8 + binLen);
+    hasBin = true;
+  }
+  return true;
+}
+
 // gltfLoad, model.h:301-460, semantics kept:
+//  * the file may be JSON text or a binary .glb; buffers may be external files (relative, %XX-decoded), base64
+//    `data:` URIs, or the .glb's BIN chunk -- what cgltf_parse_file + cgltf_load_buffers load (:301-315); any
+//    other URI scheme, a short buffer or a missing file fails the load
 //  * meshes -> primitives only; node transforms ignored (:317-320)
-//  * POSITION (vec3 f32) / TEXCOORD (vec2 f32) read from bufferView.byteOffset, accessor byteOffset and
-//    stride ignored (:343,359); indices read as u16 (:448)
+//  * POSITION (vec3 f32) / TEXCOORD_n (vec2 f32, every set, appended) read from bufferView.byteOffset, accessor
+//    byteOffset and stride ignored (:343,359); indices read as u16 whatever their component type (:448)
 //  * attribute data and triangles go to model->meshes[primIndex] -- the reference indexes by the
 //    primitive's index inside ITS gltf mesh, not by the mesh just pushed (:345,361,450): identical for
-//    a single gltf mesh, kept as is for several
-//  * images: "<data dir>/<uri>" loaded with 3 components (:420-431); material via the ctor :60-66
-//    with baseColorFactor / metallicFactor / roughnessFactor (glTF defaults 1,1,1,1 / 1 / 1)
+//    a single gltf mesh; with several meshes (data/scene.gltf) everything lands in the first primIndex entries
+//  * images: "<data dir>/<uri>" loaded with 3 components (:420-431), so an embedded image (a `data:` URI, or a
+//    .glb image that lives in a bufferView -- the reference appends a null uri there, undefined behaviour) is a
+//    FAILED load: magenta, texture.h:130-131; material via the ctor :60-66 with baseColorFactor / metallicFactor /
+//    roughnessFactor (glTF defaults 1,1,1,1 / 1 / 1)
 inline bool gltfLoad(std::string filename, shared_ptr<model> model) {
   std::ifstream in(filename, std::ios::binary);
   if (!in) return false;
   std::stringstream ss;
   ss << in.rdbuf();
-  const std::string text = ss.str();
+  const std::string file = ss.str();
+  std::string text;
+  std::vector<uint8_t> glbBin;
+  bool hasBin = false;
+  if (!srtGltfSplit(file, text, glbBin, hasBin)) return false;
   srtJson g;
   if (!srtJsonParser(text).parse(g)) return false;
   const std::string dir = filename.find_last_of('/') == std::string::npos ? "" : filename.substr(0, filename.find_last_of('/') + 1);
   std::vector<std::vector<uint8_t>> buffers;
   for (size_t i = 0; i < g["buffers"].size(); ++i) {
-    std::ifstream b(dir + g["buffers"][i]["uri"].str, std::ios::binary);
-    if (!b) return false;  // cgltf_load_buffers failure (:312-315)
-    buffers.emplace_back((std::istreambuf_iterator<char>(b)), std::istreambuf_iterator<char>());
+    const srtJson& b = g["buffers"][i];
+    const size_t size = (size_t)b["byteLength"].number(0);
+    if (!b.has("uri")) {
+      // cgltf_load_buffers: buffer 0 without a uri is the BIN chunk; any other stays without data (the reference
+      // would then read through a null pointer: fail instead)
+      if (i != 0 || !hasBin || glbBin.size() < size) return false;
+      buffers.push_back(glbBin);
+      continue;
+    }
+    const std::string& uri = b["uri"].str;
+    if (uri.compare(0, 5, "data:") == 0) {
+      const size_t comma = uri.find(',');
+      if (comma == std::string::npos || comma < 7 || uri.compare(comma - 7, 7, ";base64") != 0) return false;
+      std::vector<uint8_t> bytes;
+      if (!srtBase64Decode(uri.data() + comma + 1, uri.size() - comma - 1, size, bytes)) return false;
+      buffers.push_back(std::move(bytes));
+    } else if (uri.find("://") == std::string::npos) {
+      std::ifstream bf(dir + srtUriDecode(uri), std::ios::binary);
+      if (!bf) return false;  // cgltf_load_buffers failure (:312-315)
+      buffers.emplace_back((std::istreambuf_iterator<char>(bf)), std::istreambuf_iterator<char>());
+      if (buffers.back().size() < size) return false;
+    } else {
+      return false;  // cgltf_result_unknown_format
+    }
   }
   auto viewPtr = [&](const srtJson& accessor, size_t bytesNeeded) -> const uint8_t* {
     const srtJson& bv = g["bufferViews"][(size_t)accessor["bufferView"].number(-1)];
@@ -159,6 +257,7 @@ inline bool gltfLoad(std::string filename, shared_ptr<model> model) {
     if (texInfo.isNull()) return "";
     const srtJson& tex = g["textures"][(size_t)texInfo["index"].number(-1)];
     const srtJson& img = g["images"][(size_t)tex["source"].number(-1)];
+    // no image -> no texture; an image without a uri (embedded in a bufferView) -> "<data dir>/" which cannot be loaded
     return img.isNull() ? "" : srtDataDir() + img["uri"].str;
   };
 

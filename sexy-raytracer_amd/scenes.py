@@ -105,25 +105,57 @@ def scene_iron():
     return sb
 
 
-def add_masterchief(sb, gltf_path=None):
-    """model::create(...)->init() then objects.add(every triangle) (main.cpp:74-86)."""
-    gltf_path = gltf_path or os.path.join(ASSETS, "masterchief2-separate-xf.gltf")
-    for prim in load_gltf(gltf_path):
-        m = prim["material"]
-        # model.h:420-437: three imagePNG(…, 3); the metallicRoughness map is stored but never
-        # sampled (material.h:190-200), so metallic/roughness come from the scalar factors.
-        alb = sb.image(_load_png(m["albedo"], 3), 3) if m["albedo"] else -1
-        nrm = sb.image(_load_png(m["normal"], 3), 3) if m["normal"] else -1
+def _try_png(path, bpp):
+    """imagePNG(path, bpp): the pixels, or None for a failed load (texture.h:117-120) -- e.g. the `data:` URI of an
+    embedded image, which gltfLoad hands to stbi_load as a file name (model.h:395-412)."""
+    try:
+        return _load_png(path, bpp)
+    except (OSError, ValueError):
+        return None
+
+
+def add_model(sb, gltf_path):
+    """model::create(path)->init() then objects.add(every triangle of every mesh) (main.cpp:60-86).  A triangle's
+    material is its mesh's (model.h:108,178); all three maps are imagePNG(..., 3) (model.h:420-437) and the
+    metallicRoughness map is stored but never sampled (material.h:190-200), so metallic / roughness come from
+    the scalar factors.  Returns the number of triangles added."""
+    added = 0
+    for mesh in load_gltf(gltf_path):
+        if not len(mesh["indices"]):
+            continue
+        m = mesh["material"]
+        if m is None:
+            raise ValueError("%s: triangles on a mesh without a material (the reference dereferences a null matPtr)" % gltf_path)
+        alb = sb.image(_try_png(m["albedo"], 3), 3) if m["albedo"] else -1
+        nrm = sb.image(_try_png(m["normal"], 3), 3) if m["normal"] else -1
         mat = sb.pbr(albedo_tex=alb, normal_tex=nrm, albedo=m["baseColorFactor"],
                      metalness=m["metallicFactor"], roughness=m["roughnessFactor"])
-        sb.add_triangles(prim["positions"], prim["texcoords"], prim["indices"], mat)
+        sb.add_triangles(mesh["positions"], mesh["texcoords"], mesh["indices"], mat)
+        added += len(mesh["indices"])
+    return added
 
 
-def scene_masterchief(with_spheres=True):
-    """Config C4/C5: the main.cpp HEAD scene (main.cpp:54-154): masterchief mesh (3042 triangles),
-    ground, light sphere, iron sphere, metal sphere -> 3046 prims in one bvhNode."""
+def add_masterchief(sb, gltf_path=None):
+    """main.cpp:74-86 with the file main.cpp:74 names."""
+    return add_model(sb, gltf_path or os.path.join(ASSETS, "masterchief2-separate-xf.gltf"))
+
+
+def scene_gltf(gltf_path):
+    """The `if (0)` / `else` branches of main.cpp:60-79 (square.gltf, scene.gltf, ...): the model's triangles and
+    the checker ground in one bvhNode."""
     sb = SceneBuilder()
-    add_masterchief(sb)
+    add_model(sb, gltf_path)
+    _ground(sb)
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
+def scene_masterchief(with_spheres=True, gltf_path=None):
+    """Config C4/C5: the main.cpp HEAD scene (main.cpp:54-154): masterchief mesh (3042 triangles),
+    ground, light sphere, iron sphere, metal sphere -> 3046 prims in one bvhNode.  gltf_path: another model file in
+    the mesh's place (the square.gltf / scene.gltf branches of main.cpp:60-79)."""
+    sb = SceneBuilder()
+    add_masterchief(sb, gltf_path)
     _ground(sb)
     if with_spheres:
         sb.add_sphere((-7.0, 4.0, 6.0), 1.0, sb.light((250.2, 220.9, 110.2)))  # main.cpp:126-127

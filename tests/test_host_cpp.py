@@ -179,3 +179,134 @@ def test_cpp_png_decoder_rejects_hostile_headers(tmp_path):
     path = str(tmp_path / "good.png")
     open(path, "wb").write(good)
     assert subprocess.run([tool, "decode", path, "3", str(tmp_path / "o.raw")], capture_output=True).returncode == 0
+
+
+# ---- N1: every model file the reference ships loads the way gltfLoad loads it (model.h:301-460) ----
+REF_DATA = "/root/reference/data"
+
+
+def _fnv(b, h=1469598103934665603):
+    for x in np.frombuffer(b, np.uint8).tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _fnv_fast(arr):
+    """FNV-1a over the bytes of arr (numpy, vectorised per byte position would change the order: plain loop on small data)."""
+    return _fnv(np.ascontiguousarray(arr).tobytes())
+
+
+def _cpp_model_dump(path, data_dir):
+    exe = os.path.join(ROOT, "examples", "srt_flatten_dump")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sexy-raytracer_amd", "host")], stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe, "--model", path], env=dict(os.environ, SRT_DATA_DIR=data_dir), stdout=subprocess.PIPE,
+                       stderr=subprocess.DEVNULL, text=True)
+    meshes, flat = [], None
+    for line in r.stdout.splitlines():
+        w = line.split()
+        if w[:1] == ["mesh"]:
+            meshes.append({"positions": int(w[3]), "texcoords": int(w[5]), "triangles": int(w[7]), "material": int(w[9]),
+                           "hp": int(w[11]), "ht": int(w[13])})
+        elif w[:2] == ["flattened", "triangles"]:
+            flat = {"triangles": int(w[2]), "materials": int(w[4]), "textures": int(w[6]), "hash": int(w[8])}
+    return r.returncode, meshes, flat
+
+
+def _check_model_file(srt, path, data_dir, expect_meshes):
+    import importlib
+    gltf = importlib.import_module("sexy-raytracer_amd.gltf")
+    rc, meshes, flat = _cpp_model_dump(path, data_dir)
+    assert rc == 0, "C++ gltfLoad failed on %s" % path
+    py = gltf.load_gltf(path)
+    assert len(py) == len(meshes) == expect_meshes
+    for a, b in zip(py, meshes):
+        assert (len(a["positions"]), len(a["texcoords"]), len(a["indices"])) == (b["positions"], b["texcoords"], b["triangles"])
+        assert (a["material"] is not None) == bool(b["material"])
+        assert _fnv_fast(a["positions"]) == b["hp"] and _fnv_fast(a["texcoords"]) == b["ht"]
+    # the triangles as objects.add() sees them (main.cpp:81-85): same vertices through both loaders
+    sb = srt.abi.SceneBuilder()
+    n = srt.scenes.add_model(sb, path)
+    assert n == flat["triangles"] == sum(m["triangles"] for m in meshes)
+    tri = np.concatenate(sb.triangles)
+    h = 1469598103934665603
+    for t in tri:
+        h = _fnv(t["uv"].tobytes(), _fnv(t["p"].tobytes(), h))
+    assert h == flat["hash"]
+    return py, meshes, flat, sb
+
+
+def test_data_uri_and_glb_loading_synthetic(tmp_path, srt):
+    """cgltf_load_buffers' three buffer sources on the same mesh: external .bin (assets/), the same bytes as a base64
+    `data:` URI, and as the BIN chunk of a .glb -- identical vertices through the C++ and the Python loader; and the
+    failures gltfLoad turns into `false` (truncated base64, foreign URI scheme, bad .glb chunk magic)."""
+    import base64
+    import json
+    import shutil
+    import struct as st
+    src = os.path.join(ROOT, "assets", "masterchief2-separate-xf.gltf")
+    g = json.load(open(src))
+    raw = open(os.path.join(ROOT, "assets", g["buffers"][0]["uri"]), "rb").read()
+    for name in ("Image_0.png", "Image_1.png"):
+        shutil.copy(os.path.join(ROOT, "assets", name), tmp_path / name)
+    want = _check_model_file(srt, src, os.path.join(ROOT, "assets"), 2)[2]
+
+    uri = dict(g)
+    uri["buffers"] = [{"byteLength": len(raw), "uri": "data:application/octet-stream;base64," + base64.b64encode(raw).decode()}]
+    p_uri = str(tmp_path / "uri.gltf")
+    json.dump(uri, open(p_uri, "w"))
+    assert _check_model_file(srt, p_uri, str(tmp_path), 2)[2] == want
+
+    glb = dict(g)
+    glb["buffers"] = [{"byteLength": len(raw)}]
+    js = json.dumps(glb).encode()
+    js += b" " * (-len(js) % 4)
+    binc = raw + b"\0" * (-len(raw) % 4)
+    body = st.pack("<II", len(js), 0x4E4F534A) + js + st.pack("<II", len(binc), 0x004E4942) + binc
+    p_glb = str(tmp_path / "m.glb")
+    open(p_glb, "wb").write(b"glTF" + st.pack("<II", 2, 12 + len(body)) + body)
+    assert _check_model_file(srt, p_glb, str(tmp_path), 2)[2] == want
+
+    import importlib
+    gltf = importlib.import_module("sexy-raytracer_amd.gltf")
+    bad = []
+    trunc = dict(uri)
+    trunc["buffers"] = [{"byteLength": len(raw), "uri": uri["buffers"][0]["uri"][:2000]}]
+    bad.append(("trunc.gltf", json.dumps(trunc).encode()))
+    http = dict(uri)
+    http["buffers"] = [{"byteLength": len(raw), "uri": "http://example.invalid/m.bin"}]
+    bad.append(("http.gltf", json.dumps(http).encode()))
+    bad.append(("magic.glb", b"glTF" + st.pack("<II", 2, 12 + len(body)) + body.replace(st.pack("<I", 0x004E4942), b"XXXX", 1)))
+    bad.append(("v1.glb", b"glTF" + st.pack("<II", 1, 12 + len(body)) + body))
+    for name, data in bad:
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        assert _cpp_model_dump(p, str(tmp_path))[0] != 0, name
+        with pytest.raises(gltf.GltfError):
+            gltf.load_gltf(p)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's data/ directory is not on this machine")
+@pytest.mark.parametrize("name,meshes,triangles", [
+    ("square.gltf", 1, 2),            # main.cpp:62, base64 data: URI buffer
+    ("cube.gltf", 1, 12),             # main.cpp:61, data: URI
+    ("masterchief.gltf", 5, 4074),    # data: URI, five primitives of one mesh
+    ("masterchief2.gltf", 2, 3042),   # data: URI buffer AND embedded data: URI images (failed loads: magenta)
+    ("masterchief.glb", 5, 4074),     # binary glTF, BIN chunk
+    ("halo.glb", 2, 3042),            # binary glTF with images in bufferViews (no uri)
+    ("scene.gltf", 15, 5614),         # main.cpp:78: fifteen meshes of one primitive -> everything lands in meshes[0]
+    ("masterchief-sep.gltf", 4, 2016),
+    ("masterchief2-separate.gltf", 2, 3042),
+    ("masterchief2-separate-xf.gltf", 2, 3042),  # main.cpp:74
+])
+def test_reference_model_files_load_like_gltfload(srt, name, meshes, triangles):
+    py, cpp, flat, sb = _check_model_file(srt, os.path.join(REF_DATA, name), REF_DATA, meshes)
+    assert flat["triangles"] == triangles
+    if name == "scene.gltf":
+        # the meshes[primIndex] quirk (model.h:345,361,450): every primitive is primitive 0 of its own glTF mesh, so all
+        # vertex data and triangles pile up in meshes[0] and every triangle wears the first primitive's material
+        assert [m["triangles"] for m in cpp] == [5614] + [0] * 14 and cpp[0]["positions"] == 5740
+        assert flat["materials"] == 1
+        assert len({int(t["material"]) for t in np.concatenate(sb.triangles)}) == 1
+    if name in ("masterchief2.gltf", "halo.glb"):
+        # embedded images cannot be opened as files: imagePNG load failures, as in the reference (texture.h:117-120)
+        assert all(t.width == 0 for t in sb.textures) and len(sb.textures) == flat["textures"] == 4

@@ -24,6 +24,7 @@
 extern "C" {
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_render_occupancy(int traversal, int count, int ldsTree, size_t ldsBytes, int* blocksPerCU);
+int srt_launch_render_wf(const RenderArgs* a, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream);
 int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
@@ -230,6 +231,7 @@ struct Tunables {
   int primAgainMin;
   int keepEighths;
   int ldsTree;
+  int wavefront, wfPool, wfSwapMin, wfSwapBig;
 };
 
 struct SrtContext {
@@ -257,6 +259,8 @@ struct SrtContext {
   int32_t aovDepth = 0;
   DeviceBuffer chunkScratch;
   DeviceBuffer attScratch;  // LDS-resident-tree kernel: the lanes' attenuation stacks (srt_render_kernel LDSTREE)
+  DeviceBuffer wfPool, wfAttHi;  // path-pool kernel: contexts and upper attenuation levels (srt_wavefront.hip)
+  int32_t* dWfError = nullptr;
   DeviceBuffer tileTable;   // RenderArgs::tileXY for the image size and tile order below
   int32_t tileTableKey[3] = {0, 0, 0};
   int32_t lastLaunch[4] = {0, 0, 0, 0};  // srtGetLaunchInfo
@@ -276,6 +280,17 @@ int fail(SrtContext* ctx, const char* fmt, ...) {
   if (ctx) ctx->error = buf;
   fprintf(stderr, "srt_hip: %s\n", buf);  // the reference reports on std::cerr (texture.h:64-67, bvh.h:37-38)
   return 1;
+}
+
+// A path-pool launch that gave up (a ring wait exceeded its bound, srt_wavefront.hip) has added to the context's error
+// word: the frame is incomplete.  Checked wherever the host has waited for the device anyway.
+int wfCheck(SrtContext* ctx) {
+  if (ctx->dWfError && *(volatile int32_t*)ctx->dWfError != 0) {
+    const int n = *(volatile int32_t*)ctx->dWfError;
+    *(volatile int32_t*)ctx->dWfError = 0;
+    return fail(ctx, "render: %d workgroup(s) of the path-pool kernel gave up waiting on a ring; the frame is incomplete", n);
+  }
+  return 0;
 }
 
 #define HIP_OK(ctx, call)                                                                   \
@@ -328,6 +343,11 @@ const TunableName kTunables[] = {
     {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 12288},  // budget of the chunk-slot path
     {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 1},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
+    // the path-pool kernel (srt_wavefront.hip) for every launch the LDS-resident tree serves: 1 on, 0 off
+    {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 1},
+    {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 1536},       // path contexts per workgroup (1024 lanes traverse)
+    {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 16},
+    {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -432,6 +452,10 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 32 * sizeof(unsigned long long)));
   HIP_OK(ctx, hipEventCreate(&ctx->evStart));
   HIP_OK(ctx, hipEventCreate(&ctx->evStop));
+  // the word a path-pool workgroup that gave up adds to: host memory the device writes, so that the host can look at it
+  // without a synchronisation of its own (wfCheck)
+  HIP_OK(ctx, hipHostMalloc((void**)&ctx->dWfError, sizeof(int32_t), hipHostMallocMapped));
+  *ctx->dWfError = 0;
   *out = ctx;
   return 0;
 }
@@ -450,6 +474,9 @@ int srtDestroy(SrtContext* ctx) {
   freeScene(ctx);
   if (ctx->chunkScratch.p) (void)hipFree(ctx->chunkScratch.p);
   if (ctx->attScratch.p) (void)hipFree(ctx->attScratch.p);
+  if (ctx->wfPool.p) (void)hipFree(ctx->wfPool.p);
+  if (ctx->wfAttHi.p) (void)hipFree(ctx->wfAttHi.p);
+  if (ctx->dWfError) (void)hipHostFree(ctx->dWfError);
   if (ctx->tileTable.p) (void)hipFree(ctx->tileTable.p);
   if (ctx->dQueue) (void)hipFree(ctx->dQueue);
   if (ctx->dStats) (void)hipFree(ctx->dStats);
@@ -697,6 +724,13 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   };
   for (int i = 0; i < d->numTriangles; ++i) withFlags(triShade[4 * (size_t)i + 3].w);
   for (int i = 0; i < d->numSpheres; ++i) withFlags(spheres[3 * (size_t)i + 1].w);
+  // material class per primitive reference (DevScene::primClass; filled after the triangles have their device order)
+  auto classOf = [&](float word, bool sphere) -> uint8_t {
+    int32_t bits;
+    memcpy(&bits, &word, 4);
+    const int type = (bits >> SRT_MAT_TYPE_SHIFT) & 3;
+    return type == SRT_MAT_PBR ? (sphere ? 1 : 0) : 2;
+  };
   std::vector<uint4> shadeRecs((size_t)8 * d->numMaterials, make_uint4(0, 0, 0, 0));
   for (int i = 0; i < d->numMaterials; ++i) {
     const DevMaterial& m = mats[i];
@@ -791,8 +825,58 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       triDevIndex.swap(order);  // devRef of the device-built trees below
     }
   }
+  // ---- thread links of the LDS-resident-tree kernel (DevScene::nodeThread): bvh.h:102-103 visits left, then right,
+  // always, so "where to go when this subtree is done" is a property of the tree: the right sibling's subtree for a
+  // left child, the parent's successor for a right child, "done" for a root.  16 bits per reference (node index,
+  // ~primitive, 0x8000 = done).  Only for scenes whose trees were all built on the host out of nodes with two node
+  // children or two primitive children (bvh.h:55-95 builds nothing else; a caller-built tree may).
+  std::vector<int32_t> nodeThread;
+  {
+    const size_t n = nodes.size() / 2;
+    auto refOf = [&](size_t slot) {
+      int32_t r;
+      memcpy(&r, &nodes[slot].w, 4);
+      return r;
+    };
+    bool ok = n > 0 && n < 32767 && 2 * (int64_t)d->numTriangles < 32766 && 2 * (int64_t)d->numSpheres + 1 < 32766;
+    for (const auto& dt : ctx->itemDeviceTree) ok = ok && dt.base < 0;
+    for (size_t i = 0; ok && i < n; ++i) ok = (refOf(2 * i) >= 0) == (refOf(2 * i + 1) >= 0);
+    if (ok) {
+      const int32_t kDone = 0x8000;
+      auto ref16 = [&](int32_t r) { return (uint32_t)(r >= 0 ? SRT_NODE_INDEX(r) : r) & 0xffffu; };  // r: device reference
+      nodeThread.assign(n, (int32_t)((uint32_t)kDone << 16 | (uint32_t)kDone));
+      std::vector<uint8_t> seen(n, 0);
+      std::vector<std::pair<int32_t, uint32_t>> todo;  // (node index, its successor as 16 bits)
+      for (int32_t wr : world)
+        if (wr >= 0) todo.emplace_back(SRT_NODE_INDEX(wr), (uint32_t)kDone);
+      while (ok && !todo.empty()) {
+        const auto [i, after] = todo.back();
+        todo.pop_back();
+        if (i < 0 || (size_t)i >= n || seen[i]) {  // a node reached twice is not a tree: leave it to the stack walk
+          ok = false;
+          break;
+        }
+        seen[i] = 1;
+        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
+        if (l >= 0) {
+          nodeThread[i] = (int32_t)(after << 16 | after);
+          todo.emplace_back(SRT_NODE_INDEX(r), after);          // the right subtree is followed by this node's successor
+          todo.emplace_back(SRT_NODE_INDEX(l), ref16(r));       // the left subtree by the right child
+        } else {
+          nodeThread[i] = (int32_t)(after << 16 | (r != l ? ref16(r) : after));  // first object -> second object (or on)
+        }
+      }
+    }
+    if (!ok) nodeThread.clear();
+  }
+  std::vector<uint8_t> primClass((size_t)2 * std::max(d->numTriangles, d->numSpheres) + 2, 2);
+  for (int i = 0; i < d->numTriangles; ++i) primClass[(size_t)i << 1] = classOf(triShade[4 * (size_t)i + 3].w, false);
+  for (int i = 0; i < d->numSpheres; ++i) primClass[((size_t)i << 1) | 1] = classOf(spheres[3 * (size_t)i + 1].w, true);
   DevScene& s = ctx->scene;
   memset(&s, 0, sizeof s);
+  if (!nodeThread.empty() && uploadVec(ctx, nodeThread, &s.nodeThread)) return 1;
+  if (uploadVec(ctx, primClass, &s.primClass, 16)) return 1;
+  s.numPrimClass = (int32_t)primClass.size();
   if (uploadVec(ctx, nodeAxis, &s.nodeAxis, 64) || uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
       uploadVec(ctx, spheres, &s.spheres) || uploadVec(ctx, triPrimId, &s.triPrimId) ||
       uploadVec(ctx, sphPrimId, &s.sphPrimId) || uploadVec(ctx, world, &s.world) || uploadVec(ctx, mats, &s.materials) || uploadVec(ctx, shadeRecs, &s.shadeRecs) ||
@@ -1092,44 +1176,66 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
       HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
     }
   }
-  // FAITHFUL on a scene whose whole node array fits into a CU's LDS beside 1024 lanes' 16-bit traversal stacks: the
-  // LDS-resident-tree kernel (srt_render_kernel LDSTREE), one workgroup of 1024 threads per CU.  References must
-  // fit the 16-bit stack slots: node indices and primitive references below 2^15.
-  const size_t ldsTreeBytes = (size_t)ctx->scene.numNodes * 32 + (size_t)(ctx->scene.stackDepth + 2) * 1024 * sizeof(int16_t) + 16 * sizeof(int32_t);
+  // FAITHFUL on a scene whose whole node array fits into a CU's LDS: the LDS-resident-tree kernel (srt_render_kernel
+  // LDSTREE), one workgroup of 1024 threads per CU, walking the threaded copy of the tree (no per-lane stack).
+  const size_t ldsTreeBytes = (size_t)ctx->scene.numNodes * 32 + 16 * sizeof(int32_t);  // threaded tree: no stacks
   // (Even trees of a few dozen nodes gain: their frames are shading-bound, and the 128-register kernel keeps a hit's
   // texel loads in flight together where the 96-register one spills, profiles/r02/lds_tree.txt.)
   const bool ldsTree = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->tun.ldsTree > 0 && ctx->scene.numNodes >= ctx->tun.ldsTree && ldsTreeBytes <= 160 * 1024 &&
-                       ctx->scene.numNodes < 32767 && 2 * (int64_t)ctx->scene.numTris < 32766 && 2 * (int64_t)ctx->scene.numSpheres + 1 < 32766;
+                       ctx->scene.nodeThread != nullptr;  // thread links exist: host-built trees, 15-bit references (srtUploadScene)
   // ... and when the attenuation stacks fit behind them as well they stay in LDS (ldsTreeMode 2): +2 to +5 % on the
   // small BASELINE scenes; the headline scene's tree leaves no room (mode 1: they live in global memory)
   const size_t attBytes = (size_t)(3 * p->maxBounce + 3) * 1024 * sizeof(float);
   const int ldsTreeMode = !ldsTree ? 0 : (ldsTreeBytes + attBytes <= 160 * 1024 ? 2 : 1);
   const size_t lds = ldsTreeMode == 2 ? ldsTreeBytes + attBytes : ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
+  // The path-pool kernel (srt_wavefront.hip) serves what the LDS-resident tree serves, when its rings fit behind the
+  // tree: one 1024-thread workgroup per CU, wfPool contexts each.  The counting variant stays with srt_render_kernel.
+  int wfPoolSize = std::max(1024, std::min(16384, ctx->tun.wfPool));
+  int wfRingCap = 1;
+  while (wfRingCap < wfPoolSize) wfRingCap *= 2;
+  const size_t wfLds = (size_t)ctx->scene.numNodes * 32 + 64 * sizeof(int32_t) + (size_t)5 * wfRingCap * sizeof(uint16_t);
+  const bool wavefront = ldsTree && ctx->tun.wavefront > 0 && !p->countStats && wfLds <= 160 * 1024 && ctx->scene.primClass != nullptr;
   int perCU = 0;
-  if (srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
+  if (wavefront || srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
   const int wgWaves = ldsTree ? 16 : 4;
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * wgWaves - 1) / (SRT_TILE_PIXELS * wgWaves));
   if (grid < 1) grid = 1;
-  if (ldsTreeMode == 1) {
-    const size_t need = (size_t)(3 * p->maxBounce + 3) * grid * 1024 * sizeof(float);
-    if (ctx->attScratch.bytes < need) {
-      if (ctx->attScratch.p) HIP_OK(ctx, hipFree(ctx->attScratch.p));
-      ctx->attScratch = DeviceBuffer();
-      HIP_OK(ctx, hipMalloc(&ctx->attScratch.p, need));
-      ctx->attScratch.bytes = need;
-    }
+  auto ensure = [&](DeviceBuffer& b, size_t need) -> int {
+    if (b.bytes >= need) return 0;
+    if (b.p) HIP_OK(ctx, hipFree(b.p));
+    b = DeviceBuffer();
+    HIP_OK(ctx, hipMalloc(&b.p, need));
+    b.bytes = need;
+    return 0;
+  };
+  if (wavefront) {
+    // a workgroup never needs more contexts than it has work items
+    const int64_t itemsPerGroup = ((int64_t)a.numWork + grid - 1) / grid;
+    wfPoolSize = (int)std::max<int64_t>(64, std::min<int64_t>(wfPoolSize, itemsPerGroup + 63));
+    if (ensure(ctx->wfPool, (size_t)grid * wfPoolSize * 128)) return 1;
+    const int hiLevels = std::max(0, p->maxBounce - 4);
+    if (ensure(ctx->wfAttHi, std::max<size_t>(16, (size_t)grid * 3 * hiLevels * wfPoolSize * sizeof(float)))) return 1;
+    a.wfPool = static_cast<char*>(ctx->wfPool.p);
+    a.wfAttHi = static_cast<float*>(ctx->wfAttHi.p);
+    a.wfPoolSize = wfPoolSize;
+    a.wfRingCap = wfRingCap;
+    a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
+    a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
+    HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
+  } else if (ldsTreeMode == 1) {
+    if (ensure(ctx->attScratch, (size_t)(3 * p->maxBounce + 3) * grid * 1024 * sizeof(float))) return 1;
     a.attScratch = static_cast<float*>(ctx->attScratch.p);
   }
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  ctx->lastLaunch[0] = ldsTreeMode;
+  ctx->lastLaunch[0] = wavefront ? 3 : ldsTreeMode;
   ctx->lastLaunch[1] = grid;
   ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
-  ctx->lastLaunch[3] = (int32_t)lds;
-  int rc = srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
+  ctx->lastLaunch[3] = (int32_t)(wavefront ? wfLds : lds);
+  int rc = wavefront ? srt_launch_render_wf(&a, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;
@@ -1180,6 +1286,7 @@ int srtRenderImage(SrtContext* ctx, const SrtRenderParams* pIn, float* hAccum, u
     if (srtRenderTilesImpl(ctx, &p, dTiles, nullptr)) break;
     if (srtResolveTiles(ctx, &p, dTiles, dRgba, dAcc, nullptr)) break;
     if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "render kernel failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (wfCheck(ctx)) break;
     if (hRgba && hipMemcpy(hRgba, dRgba, nPix * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "copy rgba"); break; }
     if (hAccum && hipMemcpy(hAccum, dAcc, nPix * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) { fail(ctx, "copy accum"); break; }
     rc = 0;
@@ -1249,7 +1356,7 @@ int srtLastKernelMs(SrtContext* ctx, float* ms) {
   if (!ctx->timed) return fail(ctx, "no render has been launched");
   HIP_OK(ctx, hipEventSynchronize(ctx->evStop));
   HIP_OK(ctx, hipEventElapsedTime(ms, ctx->evStart, ctx->evStop));
-  return 0;
+  return wfCheck(ctx);
 }
 
 int srtGetStats(SrtContext* ctx, SrtStats* out) {

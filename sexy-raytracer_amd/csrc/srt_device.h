@@ -64,6 +64,17 @@ struct DevScene {
   // 1 byte per node: the axis its children are split on (left = lower side), 3 = unknown.  Read only by
   // SRT_TRAVERSE_CLOSEST, which visits the nearer child first; FAITHFUL keeps bvh.h's left-then-right.
   const uint8_t* nodeAxis;
+  // The LDS-resident-tree kernel walks the tree without a stack (bvh.h:102-103 is a fixed left-then-right order): one
+  // word per node, two 16-bit references -- low half: what follows a leaf's first object (its second object, or the high
+  // half again for a single-object leaf); high half: where the traversal goes when this node's subtree is done (node
+  // INDEX, primitive reference, or 0x8000 = done).  Null unless every tree was built on the host, every node's children
+  // are two nodes or two primitives, and every reference fits 15 bits (srt_api.cpp threadTree).
+  const int32_t* nodeThread;
+  // path-pool kernel (srt_wavefront.hip): the material CLASS of every primitive, indexed by ~reference
+  // (index << 1 | sphere): 0 triangle with a pbr material, 1 sphere with a pbr material, 2 anything else.  A hit goes to
+  // its class's ring, so a hit step runs one class's code.
+  const uint8_t* primClass;
+  int32_t numPrimClass;
   const int32_t* triPrimId;  // device index -> index into the scene's prims[] list
   const int32_t* sphPrimId;
   const int32_t* world;  // refs, world-list order
@@ -126,6 +137,14 @@ struct RenderArgs {
   int32_t unitGroups;
   float rcpUnitGroups, rcpChunks;
   const uint32_t* tileXY;
+  // path-pool kernel (srt_wavefront.hip): wfPoolSize contexts of 128 B per workgroup, the attenuation levels beyond
+  // the four a context holds ([workgroup][level - 4][channel][context]), ring capacity (a power of two >= wfPoolSize),
+  // lanes with nothing to traverse before a wave swaps finished walks for READY contexts (wfSwapMin when no full batch
+  // waits to be served, wfSwapBig regardless), and the word a workgroup that gave up (bounded spin exceeded) adds to
+  char* wfPool;
+  float* wfAttHi;
+  int32_t wfPoolSize, wfRingCap, wfSwapMin, wfSwapBig;
+  int32_t* wfError;
 };
 
 struct TraceArgs {

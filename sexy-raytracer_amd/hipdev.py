@@ -259,10 +259,12 @@ class Context:
         return [int(x) for x in out]
 
     def launch_info(self):
-        """The most recent render launch: {"lds_tree", "workgroups", "threads", "lds_bytes"} (include/srt_hip_test.h)."""
+        """The most recent render launch (include/srt_hip_test.h).  lds_tree_mode: 0 node records through the L1,
+        1 / 2 LDS-resident tree with the attenuation stacks in global memory / LDS, 3 the path-pool kernel."""
         out = np.zeros(4, np.int32)
         self._check(lib.srtGetLaunchInfo(self.h, out.ctypes.data))
-        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "workgroups": int(out[1]), "threads": int(out[2]), "lds_bytes": int(out[3])}
+        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "wavefront": int(out[0]) == 3, "workgroups": int(out[1]),
+                "threads": int(out[2]), "lds_bytes": int(out[3])}
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -54,12 +54,30 @@ def camera(dev, abi):
     return dev.make_camera(abi.default_camera_params())
 
 
-@pytest.fixture(params=[1, 0], ids=["lds_tree", "l1_nodes"])
+@pytest.fixture(params=["wavefront", "lds_tree", "l1_nodes"])
 def node_path(request, ctx):
-    """Both node paths of the FAITHFUL render kernel: the LDS-resident-tree variant (one workgroup of 1024 threads per
-    CU, the default for scenes whose node array fits a CU's LDS) and the 256-thread kernel that reads the node
-    records through the vector L1 (tunable lds_tree = 0; what larger scenes get)."""
-    default = ctx.get_tunable("lds_tree")
-    ctx.set_tunable("lds_tree", request.param)  # 1: every tree that fits, however small
+    """The three forms of the FAITHFUL render kernel: the path-pool kernel (srt_wavefront.hip: lanes traverse the
+    LDS-resident threaded tree, full waves shade contexts taken from per-class rings; the default for scenes whose node
+    array fits a CU's LDS), the step-scheduler kernel over the same LDS-resident tree (tunable wavefront = 0), and the
+    256-thread step-scheduler kernel that reads the node records through the vector L1 (lds_tree = 0; what larger
+    scenes get).  A counting launch (count_stats) of the first runs the second: the counters belong to the scene."""
+    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront")}
+    ctx.set_tunable("lds_tree", 0 if request.param == "l1_nodes" else 1)  # 1: every tree that fits, however small
+    ctx.set_tunable("wavefront", 1 if request.param == "wavefront" else 0)
     yield request.param
-    ctx.set_tunable("lds_tree", default)
+    for k, v in saved.items():
+        ctx.set_tunable(k, v)
+
+
+def render_counted(ctx, p, node_path):
+    """ctx.render_image(p) for a test that also reads ctx.stats(): the image comes from the kernel under test, the
+    counters from the counting variant.  For the path-pool kernel these are two launches (its counting variant is the
+    step-scheduler kernel over the same tree), and the image is checked to come from the path-pool kernel itself."""
+    if node_path != "wavefront" or not p.countStats:
+        return ctx.render_image(p)
+    p.countStats = 0
+    acc, rgba = ctx.render_image(p)
+    assert ctx.launch_info()["wavefront"], ctx.launch_info()
+    p.countStats = 1
+    ctx.render_image(p)
+    return acc, rgba

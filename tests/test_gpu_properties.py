@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import render_counted
+
 pytestmark = pytest.mark.gpu
 
 
@@ -236,7 +238,7 @@ def test_world_and_material_variants_vs_oracle(ctx, oracle, abi, camera, variant
     ctx.set_camera(camera)
     osc = oracle.OracleScene(sb)
     p = abi.default_render_params(160, 90, 8, 6, seed=77, count_stats=1)
-    acc, rgba = ctx.render_image(p)
+    acc, rgba = render_counted(ctx, p, node_path)
     st = ctx.stats()
     want, want_rgba, want_st = osc.render(camera, p, oracle.RNG_COUNTER, threads=4)
     assert np.array_equal(np.isnan(acc), np.isnan(want))
@@ -554,34 +556,40 @@ def test_native_gather_one_rank_and_argument_errors(dev, abi, srt, camera):
 
 
 def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camera):
-    """Scenes whose node array fits a CU's LDS render through the LDS-resident-tree variant (one workgroup of 1024
-    threads per CU, 16-bit traversal stacks, attenuation stack in global memory); larger ones and lds_tree = 0
-    through the 256-thread kernel.  Same records, same arithmetic: identical accumulators, bit for bit."""
+    """Scenes whose node array fits a CU's LDS render through the path-pool kernel (srt_wavefront.hip) or, with
+    wavefront = 0, through the step-scheduler kernel over the same LDS-resident threaded tree (one workgroup of 1024
+    threads per CU each); larger ones and lds_tree = 0 through the 256-thread kernel.  Same records, same arithmetic,
+    same samples per work item: identical accumulators, bit for bit -- single running sums and exact chunk sums."""
     import torch
     W, H = 320, 180
-    default = ctx.get_tunable("lds_tree")
-    assert default >= 1  # a node-count threshold; 1 = every tree that fits
+    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront")}
+    assert saved["lds_tree"] >= 1 and saved["wavefront"] == 1  # the defaults
     for name, spp, mb in (("masterchief", 8, 4), ("spheres", 8, 8), ("iron", 4, 4)):
         ctx.upload_scene(srt.scenes.SCENES[name]())
         ctx.set_camera(camera)
-        images = {}
-        for tree in (1, 0):
-            ctx.set_tunable("lds_tree", tree)
-            try:
-                local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
-                p = abi.default_render_params(W, H, spp, mb, seed=3)
-                ctx.render_tiles(p, local.data_ptr(), None)
-                torch.cuda.synchronize()
-                info = ctx.launch_info()
-                assert info["lds_tree"] == bool(tree), (name, tree, info)
-                # the headline mesh's tree leaves no room for the attenuation stacks (mode 1), the small trees do (mode 2)
-                assert info["lds_tree_mode"] == (0 if not tree else 1 if name == "masterchief" else 2), (name, info)
-                assert info["threads"] == (1024 if tree else 256)
-                assert info["lds_bytes"] <= 160 * 1024
-                images[tree] = local.cpu().numpy()
-            finally:
-                ctx.set_tunable("lds_tree", default)
-        assert np.array_equal(images[1].view(np.uint32), images[0].view(np.uint32)), name
+        for chunks in (0, 1):
+            images = {}
+            for path, tree, wf in (("wavefront", 1, 1), ("lds_tree", 1, 0), ("l1_nodes", 0, 0)):
+                ctx.set_tunable("lds_tree", tree)
+                ctx.set_tunable("wavefront", wf)
+                try:
+                    local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+                    p = abi.default_render_params(W, H, spp, mb, seed=3, spp_chunks=chunks)
+                    ctx.render_tiles(p, local.data_ptr(), None)
+                    torch.cuda.synchronize()
+                    ctx.last_kernel_ms()  # raises if a path-pool workgroup gave up
+                    info = ctx.launch_info()
+                    assert info["lds_tree"] == bool(tree) and info["wavefront"] == bool(wf), (name, path, info)
+                    # the headline mesh's tree leaves no room for the attenuation stacks (mode 1), the small trees do (mode 2)
+                    assert info["lds_tree_mode"] == (3 if wf else 0 if not tree else 1 if name == "masterchief" else 2), (name, info)
+                    assert info["threads"] == (1024 if tree else 256)
+                    assert info["lds_bytes"] <= 160 * 1024
+                    images[path] = local.cpu().numpy()
+                finally:
+                    for k, v in saved.items():
+                        ctx.set_tunable(k, v)
+            for path in ("wavefront", "lds_tree"):
+                assert np.array_equal(images[path].view(np.uint32), images["l1_nodes"].view(np.uint32)), (name, chunks, path)
     # a tree that does not fit: 40 000 triangles -> ~40 000 nodes, 1.3 MB
     ctx.upload_scene(srt.scenes.scene_soup(40000, seed=5, extent=6.0, size=0.1))
     ctx.set_camera(camera)

@@ -6,6 +6,8 @@ render tolerance."""
 import numpy as np
 import pytest
 
+from conftest import render_counted
+
 pytestmark = pytest.mark.gpu
 
 
@@ -83,7 +85,7 @@ def test_random_scene_trace_and_render(ctx, oracle, abi, camera, seed, node_path
         else:
             assert (~same).mean() < 5e-3  # exact ties between coincident primitives only
     p = abi.default_render_params(48, 27, 3, 5, seed=seed, count_stats=1)
-    acc, rgba = ctx.render_image(p)
+    acc, rgba = render_counted(ctx, p, node_path)
     want, want_rgba, want_st = osc.render(camera, p, oracle.RNG_COUNTER, threads=4)
     assert np.array_equal(np.isnan(acc), np.isnan(want))
     bit = (acc.view(np.uint32) == want.view(np.uint32)).all(axis=-1)

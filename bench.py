@@ -221,7 +221,7 @@ def collect_pmc(args, workload, spp, timeout_s):
             acc, cnt = {}, {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "srt_render_kernel" not in row["Kernel_Name"]:
+                    if "srt_render_" not in row["Kernel_Name"]:
                         continue
                     c = row["Counter_Name"]
                     acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
@@ -426,7 +426,7 @@ def main():
     nloc = dev.num_local_tiles(W, H, world)
     local = torch.zeros((nloc, 64, 4), dtype=torch.float32, device="cuda")
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
-    chunks = max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else dev.default_spp_chunks(spp)
+    chunks = dev.plan_spp_chunks(W, H, spp, max(1, min(args.spp_chunks, spp)) if args.spp_chunks > 0 else 0)  # what the render will use
     params = abi.default_render_params(W, H, spp, max_bounce, seed=args.seed, tile_first=rank, tile_stride=world,
                                        spp_chunks=chunks if args.spp_chunks > 0 else 0, traversal=trav)  # 0 = library plan
     stream = torch.cuda.current_stream().cuda_stream
@@ -516,9 +516,10 @@ def main():
             pmc["_samples"] = samples_per_launch
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        kernel_name = "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
-                                                                  "true" if launch["lds_tree"] else "false",
-                                                                  "true" if launch.get("lds_tree_mode") == 2 else "false")
+        kernel_name = ("srt_render_wf_kernel<true,false>" if launch.get("lds_tree_mode") == 3 else
+                       "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
+                                                                   "true" if launch["lds_tree"] else "false",
+                                                                   "true" if launch.get("lds_tree_mode") == 2 else "false"))
         line = {
             "metric": "Msamples/s (WxHxspp/s), 720p masterchief @5k spp" if args.workload == "masterchief_720p_5000spp"
                       else "Msamples/s (WxHxspp/s), " + args.workload,
@@ -535,7 +536,9 @@ def main():
             "device": info,
             "launch": {"workgroups": launch["workgroups"], "threads_per_workgroup": launch["threads"], "lds_bytes_per_workgroup": launch["lds_bytes"],
                        "node_records": "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM",
-                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") == 1 else "LDS"},
+                       "kernel_form": ("path pool: lanes traverse, full waves shade contexts from per-class LDS rings (srt_wavefront.hip)"
+                                       if launch.get("lds_tree_mode") == 3 else "step scheduler: one path per lane (srt_kernels.hip)"),
+                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") in (1, 3) else "LDS"},
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),
         }

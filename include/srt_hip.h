@@ -197,11 +197,15 @@ typedef struct SrtRenderParams {
   /* One work item = one pixel x one chunk of its samples.  Samples are summed in index order inside a
    * chunk (a float running sum, main.cpp:217).  1 = a single running sum per pixel, the reference's order
    * (main.cpp:204-218), bit-reproducible against the oracle.  > 1: the chunks' float sums are added EXACTLY
-   * (64-bit fixed point with 2^-36 resolution, integer atomics) and rounded to float once, so the pixel sum
-   * does not depend on the order in which chunks finish, on the tile split or on the GPU count, and needs
-   * 32 bytes of scratch per pixel whatever the chunk count; it differs from the single running sum only by
-   * the re-association of the float sum (<= 2e-5 relative).  0 = library default
-   * srtDefaultSppChunks(spp) (fastest). */
+   * (64-bit fixed point with 2^-36 resolution) and rounded to float once, so the pixel sum does not depend on
+   * the order in which chunks finish, on the tile split or on the GPU count; it differs from the single
+   * running sum only by the re-association of the float sum (<= 2e-5 relative), and a chunk sum of
+   * 2^26 / (chunk count rounded up to a power of two) or more counts as infinite (the pixel is white either
+   * way).  Device memory held by the context until srtDestroy: 16 bytes per pixel PER CHUNK of this rank's
+   * tiles (one slot per work item, summed by a second kernel) while that fits a budget -- the smaller of
+   * 12 GiB (tunable chunk_scratch_mb) and a quarter of the free device memory --, otherwise, or when that
+   * allocation fails, 32 bytes per pixel whatever the chunk count (64-bit integer atomics, 0.4-1 % slower);
+   * both give the same bits.  0 = library default, srtPlanSppChunks(width, height, spp, 0) (fastest). */
   int32_t sppChunks;
   int32_t countStats; /* 1: run the counting variant and fill srtGetStats() */
   /* progressive rendering: this call renders samples [sampleFirst, sampleFirst + spp) of every
@@ -270,6 +274,11 @@ int32_t srtNumTiles(int32_t imageWidth, int32_t imageHeight);
 int32_t srtNumLocalTiles(int32_t imageWidth, int32_t imageHeight, int32_t tileStride);
 
 int32_t srtDefaultSppChunks(int32_t spp);
+/* The chunk count a render will use: sppChunks itself when > 0 (-1 if that many chunk slots over the whole image do
+ * not fit the kernels' 32-bit work-item index: srtRenderTiles then fails), else srtDefaultSppChunks(spp), lowered only
+ * for images beyond ~3 Mpixels.  A function of the image size and the sample count alone -- never of the tile split --
+ * so that every rank of every split adds the same chunks.  Host only. */
+int32_t srtPlanSppChunks(int32_t imageWidth, int32_t imageHeight, int32_t spp, int32_t sppChunks);
 
 /* The hot path.  Asynchronous on `stream` (a hipStream_t, NULL = default).
  * dAccumTiles: DEVICE pointer, float4[numLocalTiles * 64], tile-major,

@@ -24,9 +24,9 @@
 extern "C" {
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_render_occupancy(int traversal, int count, int ldsTree, size_t ldsBytes, int* blocksPerCU);
-int srt_launch_render_wf(const RenderArgs* a, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream);
-int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream);
+int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, float limit, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
 int srt_launch_trace(const TraceArgs* a, int traversal, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
@@ -231,7 +231,7 @@ struct Tunables {
   int primAgainMin;
   int keepEighths;
   int ldsTree;
-  int wavefront, wfPool, wfSwapMin, wfSwapBig;
+  int wavefront, wfPool, wfSwapMin, wfSwapBig, wfProfile;
 };
 
 struct SrtContext {
@@ -343,11 +343,13 @@ const TunableName kTunables[] = {
     {"keep_eighths", "SRT_KEEP_EIGHTHS", &Tunables::keepEighths, -1},
     {"chunk_scratch_mb", "SRT_CHUNK_SCRATCH_MB", &Tunables::chunkScratchMb, 12288},  // budget of the chunk-slot path
     {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 1},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
-    // the path-pool kernel (srt_wavefront.hip) for every launch the LDS-resident tree serves: 1 on, 0 off
-    {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 1},
-    {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 1536},       // path contexts per workgroup (1024 lanes traverse)
+    // the path-pool kernel (srt_wavefront.hip) for the launches the LDS-resident tree serves whose tree has at least this
+    // many nodes (traversal-heavy frames gain, shading-heavy ones with tiny trees lose: profiles/r03/wavefront.txt); 0 = never
+    {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 2048},
+    {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 2048},       // path contexts per workgroup (1024 lanes traverse)
     {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 16},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
+    {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
@@ -449,7 +451,7 @@ int srtCreate(int deviceOrdinal, SrtContext** out) {
   HIP_OK(ctx, hipSetDevice(deviceOrdinal));
   HIP_OK(ctx, hipGetDeviceProperties(&ctx->prop, deviceOrdinal));
   HIP_OK(ctx, hipMalloc((void**)&ctx->dQueue, SRT_MAX_QUEUES * 16 * sizeof(int32_t)));
-  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 32 * sizeof(unsigned long long)));
+  HIP_OK(ctx, hipMalloc((void**)&ctx->dStats, 96 * sizeof(unsigned long long)));
   HIP_OK(ctx, hipEventCreate(&ctx->evStart));
   HIP_OK(ctx, hipEventCreate(&ctx->evStop));
   // the word a path-pool workgroup that gave up adds to: host memory the device writes, so that the host can look at it
@@ -1041,6 +1043,21 @@ int32_t srtDefaultSppChunks(int32_t spp) {
   return std::max(1, std::min(640, std::max(bySize, byCount)));
 }
 
+// The chunk count a render of this size will use: `sppChunks` when the caller gives one, else srtDefaultSppChunks(spp),
+// and -1 when an explicit count does not fit.  Work items and chunk slots are indexed with 32-bit integers in the
+// kernels: the slots of one chunk over the WHOLE image (not a rank's share: the plan, and with it the image bit for
+// bit, must not depend on the tile split), plus the padding a work queue's last unit can add (a unit is at most 1024
+// tiles; every queue counts its own items).  1280 x 720 allows 2166 chunks, 1920 x 1080 1003: the default plan
+// (at most 640) always fits images below about 3 Mpixels; beyond that the default is clamped.
+int32_t srtPlanSppChunks(int32_t imageWidth, int32_t imageHeight, int32_t spp, int32_t sppChunks) {
+  if (imageWidth < 1 || imageHeight < 1 || spp < 1 || sppChunks < 0 || sppChunks > spp) return -1;
+  const int64_t perChunk = ((int64_t)srtNumTiles(imageWidth, imageHeight) + 1024 + 64) * SRT_TILE_PIXELS;
+  const int64_t maxChunks = (int64_t)0x7fffffff / perChunk;
+  if (maxChunks < 1) return -1;
+  if (sppChunks > 0) return sppChunks <= maxChunks ? sppChunks : -1;
+  return (int32_t)std::min<int64_t>(srtDefaultSppChunks(spp), maxChunks);
+}
+
 static int checkParams(SrtContext* ctx, const SrtRenderParams* p) {
   if (!ctx->haveScene) return fail(ctx, "render: no scene uploaded");
   if (!ctx->haveCamera) return fail(ctx, "render: no camera set");
@@ -1097,16 +1114,15 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.numQueues = std::min(SRT_MAX_QUEUES, std::max(1, ctx->tun.queues > 0 ? ctx->tun.queues : std::min(byUnits, byGroups)));
   }
   {
-    // work items and output slots are indexed with 32-bit integers in the kernel (queue counters run over
-    // whole units, so count the padding of the last unit of every queue too)
-    // (the whole image's tile count, not this rank's: the clamp must not depend on the tile split)
-    const int64_t perChunk = ((int64_t)a.numTiles + (int64_t)1024 * SRT_MAX_QUEUES) * SRT_TILE_PIXELS;  // 1024 = the largest unit
-    const int64_t maxChunks = (int64_t)0x7fffffff / std::max<int64_t>(perChunk, 1);
-    if (maxChunks < 1) return fail(ctx, "render: image too large (%d local tiles)", a.numLocalTiles);
-    if (a.sppChunks > maxChunks) {
-      if (p->sppChunks > 0) return fail(ctx, "render: sppChunks %d x %d tiles exceeds 2^31 work items", p->sppChunks, a.numLocalTiles);
-      a.sppChunks = (int32_t)maxChunks;
-    }
+    const int32_t planned = srtPlanSppChunks(p->imageWidth, p->imageHeight, p->spp, p->sppChunks);
+    if (planned < 1) return fail(ctx, "render: sppChunks %d x %d tiles exceeds 2^31 work items", p->sppChunks, a.numTiles);
+    a.sppChunks = planned;
+  }
+  {
+    // exact chunk sums cannot wrap: partial sums of 2^26 / (chunk count rounded up to a power of two) or more count as infinite
+    int pow2 = 1;
+    while (pow2 < a.sppChunks) pow2 *= 2;
+    a.fixLimit = 0x1p26f / (float)pow2;
   }
   a.numWork = a.numLocalTiles * a.sppChunks * SRT_TILE_PIXELS;
   a.sppBase = a.spp / a.sppChunks;
@@ -1147,7 +1163,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   a.primAgainMin = std::max(1, ctx->tun.primAgainMin);
   a.keepEighths = std::min(8, ctx->tun.keepEighths >= 0 ? ctx->tun.keepEighths : (closestMode ? 6 : 4));
   a.queue = ctx->dQueue;
-  a.stats = p->countStats ? ctx->dStats : nullptr;
+  a.stats = (p->countStats || ctx->tun.wfProfile > 0) ? ctx->dStats : nullptr;
   a.aov = p->countStats ? ctx->dAov : nullptr;
   a.aovDepth = ctx->aovDepth;
   const size_t tilePixels = (size_t)a.numLocalTiles * SRT_TILE_PIXELS;
@@ -1160,12 +1176,23 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     // srt_sum_chunks_kernel) while this rank's slots fit the budget, else the atomic path (32 B per pixel, 0.4-1 %
     // slower); the two give the same bits, so the choice may differ from rank to rank.
     const size_t localSlots = tilePixels * a.sppChunks * sizeof(float4);
-    scratchPath = localSlots <= (size_t)std::max(0, ctx->tun.chunkScratchMb) * 1024 * 1024;
-    const size_t need = scratchPath ? tilePixels * a.sppChunks * sizeof(float4) : tilePixels * sizeof(SrtFixedAccum);
+    // budget: the tunable, and never more than a quarter of what the device has free right now (a smaller, shared or
+    // partitioned GPU takes the atomic path -- same bits -- instead of failing)
+    size_t budget = (size_t)std::max(0, ctx->tun.chunkScratchMb) * 1024 * 1024, freeB = 0, totalB = 0;
+    if (ctx->chunkScratch.bytes < localSlots && hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, (freeB + ctx->chunkScratch.bytes) / 4);
+    scratchPath = localSlots <= budget;
+    size_t need = scratchPath ? localSlots : tilePixels * sizeof(SrtFixedAccum);
     if (ctx->chunkScratch.bytes < need) {
       if (ctx->chunkScratch.p) HIP_OK(ctx, hipFree(ctx->chunkScratch.p));
       ctx->chunkScratch = DeviceBuffer();
-      HIP_OK(ctx, hipMalloc(&ctx->chunkScratch.p, need));
+      if (hipMalloc(&ctx->chunkScratch.p, need) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->chunkScratch.p = nullptr;
+        if (!scratchPath) return fail(ctx, "render: cannot allocate %zu B for the pixel sums", need);
+        scratchPath = false;  // the slots do not fit after all: 32 B per pixel on the atomic path
+        need = tilePixels * sizeof(SrtFixedAccum);
+        HIP_OK(ctx, hipMalloc(&ctx->chunkScratch.p, need));
+      }
       ctx->chunkScratch.bytes = need;
     }
     if (scratchPath) {
@@ -1173,7 +1200,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
       a.chunkStride = (int32_t)tilePixels;
     } else {
       a.fix = static_cast<SrtFixedAccum*>(ctx->chunkScratch.p);
-      HIP_OK(ctx, hipMemsetAsync(a.fix, 0, need, stream));
+      HIP_OK(ctx, hipMemsetAsync(a.fix, 0, tilePixels * sizeof(SrtFixedAccum), stream));
     }
   }
   // FAITHFUL on a scene whose whole node array fits into a CU's LDS: the LDS-resident-tree kernel (srt_render_kernel
@@ -1191,11 +1218,29 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   // The path-pool kernel (srt_wavefront.hip) serves what the LDS-resident tree serves, when its rings fit behind the
   // tree: one 1024-thread workgroup per CU, wfPool contexts each.  The counting variant stays with srt_render_kernel.
-  int wfPoolSize = std::max(1024, std::min(16384, ctx->tun.wfPool));
-  int wfRingCap = 1;
-  while (wfRingCap < wfPoolSize) wfRingCap *= 2;
-  const size_t wfLds = (size_t)ctx->scene.numNodes * 32 + 64 * sizeof(int32_t) + (size_t)5 * wfRingCap * sizeof(uint16_t);
-  const bool wavefront = ldsTree && ctx->tun.wavefront > 0 && !p->countStats && wfLds <= 160 * 1024 && ctx->scene.primClass != nullptr;
+  // LDS behind the tree: 64 control words, six rings of 16-bit slots, and per context the (t, primitive) its walk ended at:
+  // 18 bytes per context.  Ring capacity = pool size = the largest of 1024, 1536, 2048, 3072, 4096 that fits and does not
+  // exceed the tunable (the headline scene's 129 KB tree leaves room for 1536).
+  int wfPoolSize = 0, wfRingCap = 0, wfRingShift = 0, wfRingMul3 = 0;
+  const size_t wfFixed = (size_t)ctx->scene.numNodes * 32 + 64 * sizeof(int32_t);
+  {
+    // ring counters are 32-bit and a 3 * 2^j ring cannot take their wrap-around: such rings only while a workgroup's
+    // enqueues stay far below 2^32 (about three per sample)
+    const double enqueuesPerGroup = 4.0 * (double)a.numLocalTiles * SRT_TILE_PIXELS * (double)p->spp / std::max(1, ctx->prop.multiProcessorCount);
+    static const struct { int cap, shift, mul3; } kRings[] = {{4096, 12, 0}, {3072, 10, 1}, {2048, 11, 0}, {1536, 9, 1}, {1024, 10, 0}};
+    for (const auto& r : kRings) {
+      if (r.cap > std::max(1024, ctx->tun.wfPool) || wfFixed + (size_t)18 * r.cap > 160 * 1024) continue;
+      if (r.mul3 && enqueuesPerGroup > 2.0e9) continue;
+      wfRingCap = r.cap;
+      wfRingShift = r.shift;
+      wfRingMul3 = r.mul3;
+      break;
+    }
+    wfPoolSize = wfRingCap;
+  }
+  const size_t wfLds = wfFixed + (size_t)18 * wfRingCap;
+  const bool wavefront = ldsTree && ctx->tun.wavefront > 0 && ctx->scene.numNodes >= ctx->tun.wavefront && !p->countStats && wfRingCap > 0 &&
+                         ctx->scene.primClass != nullptr;
   int perCU = 0;
   if (wavefront || srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
@@ -1221,6 +1266,8 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfAttHi = static_cast<float*>(ctx->wfAttHi.p);
     a.wfPoolSize = wfPoolSize;
     a.wfRingCap = wfRingCap;
+    a.wfRingShift = wfRingShift;
+    a.wfRingMul3 = wfRingMul3;
     a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
@@ -1229,13 +1276,13 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.attScratch = static_cast<float*>(ctx->attScratch.p);
   }
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
-  if (p->countStats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 32 * sizeof(unsigned long long), stream));
+  if (a.stats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 96 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
   ctx->lastLaunch[0] = wavefront ? 3 : ldsTreeMode;
   ctx->lastLaunch[1] = grid;
   ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
   ctx->lastLaunch[3] = (int32_t)(wavefront ? wfLds : lds);
-  int rc = wavefront ? srt_launch_render_wf(&a, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
+  int rc = wavefront ? srt_launch_render_wf(&a, ctx->tun.wfProfile > 0, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;
@@ -1243,7 +1290,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     rc = srt_launch_finalize(a.fix, static_cast<float4*>(dAccumTiles), (int)tilePixels, a.spp, stream);
     if (rc) return fail(ctx, "finalize launch failed: %s", hipGetErrorString((hipError_t)rc));
   } else if (scratchPath) {
-    rc = srt_launch_sum_chunks(a.out, static_cast<float4*>(dAccumTiles), (int)tilePixels, a.sppChunks, stream);
+    rc = srt_launch_sum_chunks(a.out, static_cast<float4*>(dAccumTiles), (int)tilePixels, a.sppChunks, a.fixLimit, stream);
     if (rc) return fail(ctx, "chunk sum launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
   return 0;
@@ -1435,6 +1482,15 @@ int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4) {
   memcpy(out4, ctx->lastLaunch, sizeof ctx->lastLaunch);
   return 0;
 }
+int srtGetWfProfile(SrtContext* ctx, uint64_t* out40) {
+  uint64_t* const out29 = out40;
+  if (!ctx || !out29) return 1;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  HIP_OK(ctx, hipDeviceSynchronize());
+  HIP_OK(ctx, hipMemcpy(out29, ctx->dStats + 32, 40 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10) {
   if (!ctx || !out10) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));

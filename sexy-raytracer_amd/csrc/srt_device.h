@@ -128,6 +128,7 @@ struct RenderArgs {
                     // directly); scratch path: chunk slots [chunk][localTile][64]
   int32_t chunkStride;  // scratch path: numLocalTiles * 64, else 0
   SrtFixedAccum* fix;   // atomic path: [localTile][64], items add their fixed-point partial sums here (null otherwise)
+  float fixLimit;       // exact chunk sums: a partial sum of this much or more counts as infinite (toFixed36)
   unsigned long long* stats;  // 8 counters (SrtStats order) or nullptr
   SrtAovRecord* aov;          // counting variant only: per-pixel record of the ray at bounce aovDepth (srtRenderAov)
   int32_t aovDepth;
@@ -144,6 +145,7 @@ struct RenderArgs {
   char* wfPool;
   float* wfAttHi;
   int32_t wfPoolSize, wfRingCap, wfSwapMin, wfSwapBig;
+  int32_t wfRingShift, wfRingMul3;  // wfRingCap = (wfRingMul3 ? 3 : 1) << wfRingShift
   int32_t* wfError;
 };
 

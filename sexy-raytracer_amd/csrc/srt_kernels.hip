@@ -523,7 +523,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
           // work item finished (or none yet): write it, pull the next one with one atomic per wave
           if (outIndex >= 0) {
             if (a.fix)
-              commitFixed(a.fix + outIndex, acc);
+              commitFixed(a.fix + outIndex, acc, a.fixLimit);
             else
               a.out[outIndex] = make_float4(acc.x, acc.y, acc.z, (float)sCount);
           }
@@ -662,7 +662,7 @@ __global__ void srt_finalize_kernel(const SrtFixedAccum* fix, float4* out, int n
 }
 
 // scratch path: the same exact sum over the chunk slots buf[c][i]
-__global__ void srt_sum_chunks_kernel(const float4* buf, float4* out, int n, int chunks) {
+__global__ void srt_sum_chunks_kernel(const float4* buf, float4* out, int n, int chunks, float limit) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   long long sum[3] = {0, 0, 0};
@@ -674,7 +674,7 @@ __global__ void srt_sum_chunks_kernel(const float4* buf, float4* out, int n, int
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       long long q;
-      if (toFixed36(ch[k], q))
+      if (toFixed36(ch[k], limit, q))
         sum[k] += q;
       else
         flags |= nonFiniteFlag(ch[k], k);
@@ -842,8 +842,8 @@ int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int sample
   return (int)hipGetLastError();
 }
 
-int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, hipStream_t stream) {
-  hipLaunchKernelGGL(srt_sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, buf, out, n, chunks);
+int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, float limit, hipStream_t stream) {
+  hipLaunchKernelGGL(srt_sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, buf, out, n, chunks, limit);
   return (int)hipGetLastError();
 }
 

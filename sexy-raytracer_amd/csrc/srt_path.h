@@ -754,11 +754,13 @@ __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, 
 // A float of 2^-12 or more converts exactly (its ulp is >= 2^-36; smaller ones are truncated to 2^-36
 // absolute), so two chunk sums a, b >= 2^-12 give fl(a + b) bit for bit.  NaN / infinite partial sums (the
 // r = 0 ground BRDF produces NaN samples) poison the channel as they would a float sum.
-// Range: |pixel sum| < 2^27 (partial sums beyond 2^26 count as infinite).
-// Returns false for a value that is not representable (NaN / infinite / too large).
-__device__ __forceinline__ bool toFixed36(float v, long long& q) {
+// Range: a partial sum of `limit` or more counts as infinite, limit = 2^26 / (sppChunks rounded up to a power of two)
+// (RenderArgs::fixLimit: 2^16 at the 640-chunk cap), so that the 64-bit sum of a pixel's chunks stays below 2^62 units and
+// cannot wrap.  Such a pixel resolves to white either way: a chunk of ~8 samples summing to 65 536 is a mean radiance of
+// thousands.  Returns false for a value that is not representable (NaN / infinite / at or beyond the limit).
+__device__ __forceinline__ bool toFixed36(float v, float limit, long long& q) {
   const float av = fabsf(v);
-  if (!(av < 0x1p26f)) return false;
+  if (!(av < limit)) return false;
   // |v| = hi + fr with hi = trunc(|v|) < 2^26 and fr in [0, 1), both exact; fixed = hi * 2^36 + trunc(fr * 2^36)
   const uint32_t hi = (uint32_t)av;
   const float fr = av - (float)hi;
@@ -778,14 +780,14 @@ __device__ __forceinline__ float fromFixed36(long long q, uint32_t flags, int k)
   if (ninf) return -SRT_INF;
   return (float)((double)q * 0x1p-36);
 }
-__device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc) {
+__device__ __forceinline__ void commitFixed(SrtFixedAccum* f, V3 acc, float limit) {
   const float c[3] = {acc.x, acc.y, acc.z};
   long long* const ch = &f->r;
   uint32_t flags = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     long long q;
-    if (!toFixed36(c[k], q))
+    if (!toFixed36(c[k], limit, q))
       flags |= nonFiniteFlag(c[k], k);
     else if (q != 0)
       atomicAdd(reinterpret_cast<unsigned long long*>(ch + k), (unsigned long long)q);

@@ -8,17 +8,18 @@
 // metal AND light code on every execution.  Here, with one 1024-thread workgroup owning the CU and its LDS:
 //
 //   * a PATH CONTEXT (one work item in flight: pixel x sample chunk, its current ray, RNG, attenuations, partial
-//     sum: 128 bytes in global memory, L2-resident) belongs to no lane.  Each workgroup owns `poolSize` of them
+//     sum: one 128-byte line in global memory) belongs to no lane.  Each workgroup owns `poolSize` of them
 //     (about 1.5 per lane).
 //   * lanes are TRAVERSAL ENGINES: a lane holds only a ray and its walk of the threaded tree (DevScene::nodeThread,
-//     bvh.h:97-105 in bvh.h's order).  When the walk ends it writes (t, primitive) into the context, hands the
-//     context to a queue and takes the next READY context (swap step).
+//     bvh.h:97-105 in bvh.h's order).  When the walk ends it leaves (t, primitive) in the context's LDS slot, hands the
+//     context to a queue and takes the next READY context (swap step: LDS traffic only, plus the new ray's one line).
 //   * queues are rings of context ids in LDS: READY (a fresh ray to traverse), RESTART (path ended or ray missed:
-//     main.cpp:39-40,49-51,217 and the next camera ray, main.cpp:204-216) and one HIT ring per MATERIAL CLASS
-//     (triangle + pbr / sphere + pbr / everything else).  Any wave that finds 64 entries in a ring takes them and
-//     runs that step for them: hit shading (main.cpp:42-51 + material.h) and restarts run at 64 of 64 lanes, and
-//     a hit step executes one class's code.  A wave with nothing to traverse serves partial batches, which also
-//     drains the end of the frame.
+//     main.cpp:39-40,49-51,217 and the next camera ray, main.cpp:204-216), NEWITEM (the item's last sample is in:
+//     write its sum, pull the next work item with ONE atomic for the 64, main.cpp:200-203) and one HIT ring per
+//     MATERIAL CLASS (triangle + pbr / sphere + pbr / everything else).  Any wave that finds 64 entries in a ring takes
+//     them and runs that step for them: hit shading (main.cpp:42-51 + material.h), restarts and item pulls run at 64 of
+//     64 lanes, and a hit step executes one class's code.  A wave with nothing to traverse serves partial batches,
+//     which also drains the end of the frame.
 //
 // Same arithmetic as srt_kernels.hip (srt_path.h holds it), same samples in the same order per work item, the same
 // exact chunk sums: accumulators are bit-identical to the step-scheduler kernels' (tests: node_path "wavefront").
@@ -32,18 +33,22 @@
 #define WF_RING_READY 0
 #define WF_RING_RESTART 1
 #define WF_RING_HIT 2                   // + material class
-#define WF_RINGS (2 + WF_CLASSES)
+#define WF_RING_NEWITEM (2 + WF_CLASSES)
+#define WF_RINGS (3 + WF_CLASSES)
 #define WF_SPIN_LIMIT (1 << 24)
 #define WF_CTX_BYTES 128
-// control words (LDS, behind the tree): 0..15 the waves' current work queue; 16 + 2r / 17 + 2r ring r's tail (reserved)
-// and head (claimed); 32 live contexts; 33 abort
+// Context line (global memory, one per context id):  +0 A = ray origin, time   +16 B = ray direction (terminal radiance
+// once the path has ended), -   +32 C = RNG state (2 words), -, depth | pend << 8   +48 D = partial pixel sum, sample
+// count of the item   +64 E = output index, next sample, end sample, px | py << 16   +80 attenuations of bounces 0..3
+// Control words (LDS, behind the tree): 0..15 the waves' current work queue; 16 + 2r ring r's tail (places reserved),
+// 17 + 2r its head (places claimed) -- one 8-byte read gets both --, 28 live contexts, 29 abort.  Behind them the rings
+// (16-bit slots), then per context the t (float) and the primitive (16 bits) its last walk ended at.
 #define WF_CTL_TAIL(r) (16 + 2 * (r))
 #define WF_CTL_HEAD(r) (17 + 2 * (r))
-#define WF_CTL_LIVE 32
-#define WF_CTL_ABORT 33
+#define WF_CTL_LIVE 28
+#define WF_CTL_ABORT 29
 #define WF_CTL_WORDS 64
-// context meta word: depth | pend << 8
-#define WF_PEND_NONE 3  // nothing to add (fresh context, empty item)
+#define WF_PEND_MISS 0      // context meta word: depth | pend << 8
 #define WF_PEND_TERMINAL 2
 #define WF_WG __HIP_MEMORY_SCOPE_WORKGROUP
 
@@ -59,8 +64,11 @@ __device__ __forceinline__ void bufStore1(Rsrc r, int off, uint32_t v) { __built
 __device__ __forceinline__ uint32_t bufLoad1(Rsrc r, int off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
 }  // namespace
 
-// SINGLE: the world list is one tree (as in srt_render_kernel)
-template <bool SINGLE>
+// SINGLE: the world list is one tree (as in srt_render_kernel).  PROFILE (tunable wf_profile, tools/wf_profile.py): per
+// step kind, the clocks the waves spent in it, its executions and the lanes they served -> RenderArgs::stats[32 + ...]
+// (kinds: 0 node visit, 1 primitive test, 2 swap, 3-5 hit step per class, 6 restart, 7 idle, 8 lost claim, 9 item pull).
+#define WF_PROF_KINDS 10
+template <bool SINGLE, bool PROFILE>
 __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const RenderArgs a) {
   constexpr int32_t DONE = (int32_t)0xFFFF8000;       // the 16-bit "no reference", sign-extended
   constexpr int32_t DONE_PAIR = (int32_t)0x80008000;  // both halves of a thread link
@@ -69,8 +77,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   char* const ldsTree = reinterpret_cast<char*>(lds);
   const int treeBytes = sc.numNodes * 32;
   int32_t* const ctl = reinterpret_cast<int32_t*>(ldsTree + treeBytes);
+  const int RCAP = a.wfRingCap, POOL = a.wfPoolSize;
   uint16_t* const ringSlots = reinterpret_cast<uint16_t*>(ctl + WF_CTL_WORDS);
-  const int RCAP = a.wfRingCap, RMASK = RCAP - 1, POOL = a.wfPoolSize;
+  float* const hitT = reinterpret_cast<float*>(ringSlots + WF_RINGS * RCAP);
+  uint16_t* const hitPrim = reinterpret_cast<uint16_t*>(hitT + POOL);
   const int lane = threadIdx.x & 63;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
   const uint64_t seedMixed = mix64(a.seed);
@@ -80,15 +90,24 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   const Rsrc rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
   const Rsrc rsTexels = makeRsrc(sc.texels, sc.texelBytes);
   const Rsrc rsClass = makeRsrc(sc.primClass, sc.numPrimClass);
-  // this workgroup's contexts: id << 7 is a context's byte offset; its upper attenuation levels (bounce >= 4) live in
-  // [level - 4][channel][id] behind the pools
+  // this workgroup's contexts: id << 7 is a context's byte offset; attenuation levels of bounces >= 4 live in
+  // [level - 4][channel][id] in a second array
   const Rsrc rsPool = makeRsrc(a.wfPool + (size_t)blockIdx.x * POOL * WF_CTX_BYTES, POOL * WF_CTX_BYTES);
   const int hiLevels = a.maxBounce > 4 ? a.maxBounce - 4 : 0;
   const Rsrc rsAttHi = makeRsrc(a.wfAttHi + (size_t)blockIdx.x * 3 * hiLevels * POOL, 3 * hiLevels * POOL * 4);
   const bool singleRoot = SINGLE || sc.numWorld == 1;
   auto localRef = [&](int r) { return r >= 0 ? r >> 5 : r; };
+  // place of counter value c in a ring: c mod RCAP, RCAP = 2^j or 3 * 2^j (the pool size rounded up to such a number)
+  const int ringShift = a.wfRingShift;
+  const bool ringMul3 = a.wfRingMul3 != 0;
+  auto ringPos = [&](uint32_t c) -> int {
+    if (!ringMul3) return (int)(c & (uint32_t)(RCAP - 1));
+    const uint32_t x = c >> ringShift;
+    const uint32_t x3 = x - 3u * (uint32_t)(((unsigned long long)x * 0xAAAAAAABull) >> 33);
+    return (int)((c & ((1u << ringShift) - 1u)) | (x3 << ringShift));
+  };
 
-  // ---- set-up: the threaded tree into LDS (as srt_render_kernel LDSTREE), empty rings, every context in RESTART
+  // ---- set-up: the threaded tree into LDS (as srt_render_kernel LDSTREE), empty rings, every context waits for an item
   {
     float4* dst = reinterpret_cast<float4*>(ldsTree);
     for (int i = threadIdx.x; i < sc.numNodes * 2; i += WF_BLOCK) {
@@ -103,19 +122,13 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     for (int i = threadIdx.x; i < WF_CTL_WORDS; i += WF_BLOCK) ctl[i] = 0;
     for (int i = threadIdx.x; i < WF_RINGS * RCAP; i += WF_BLOCK) ringSlots[i] = 0;
     __syncthreads();
-    for (int id = threadIdx.x; id < POOL; id += WF_BLOCK) {
-      ringSlots[WF_RING_RESTART * RCAP + id] = (uint16_t)(id + 1);
-      const int at = id << 7;
-      bufStore4(rsPool, at + 32, make_float4(0.0f, 0.0f, __int_as_float(DONE), __int_as_float(WF_PEND_NONE << 8)));
-      bufStore4(rsPool, at + 48, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-      bufStore4(rsPool, at + 64, make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f));  // outIndex, s, sEnd, px | py << 16
-    }
+    for (int id = threadIdx.x; id < POOL; id += WF_BLOCK) ringSlots[WF_RING_NEWITEM * RCAP + id] = (uint16_t)(id + 1);
     if (threadIdx.x == 0) {
-      ctl[WF_CTL_TAIL(WF_RING_RESTART)] = POOL;
+      ctl[WF_CTL_TAIL(WF_RING_NEWITEM)] = POOL;
       ctl[WF_CTL_LIVE] = POOL;
     }
     if (threadIdx.x < 16) ctl[threadIdx.x] = (int)(blockIdx.x % (unsigned)a.numQueues);  // the waves' home work queue
-    __syncthreads();  // includes the wait for the context stores
+    __syncthreads();
   }
   int32_t* const waveQueue = ctl + (threadIdx.x >> 6);
   const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
@@ -128,15 +141,32 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   // ---- rings.  A slot holds id + 1, 0 = empty.  Producers reserve places with one atomic per wave and fill them;
   // consumers claim places (compare-and-swap on the head, never beyond the tail) and take the ids, waiting the few
   // cycles a reserved place may still be unwritten.  Slots are re-used only after their consumer emptied them.
-  auto enqueue = [&](int r, bool want, int id) {
-    const unsigned long long m = __ballot(want);
-    if (m == 0) return;
-    const int leader = __ffsll((long long)m) - 1;
+  // What a producer wrote for the context BEFORE (global stores: the caller fences; LDS: one wave's LDS operations
+  // execute in order) is visible to the consumer that finds the id.
+  // `ring` < 0: this lane enqueues nothing.  All rings of one call are served together: one atomic per ring, issued side
+  // by side by the first lanes of the wave, then one look at the slots: two LDS round trips whatever the number of rings.
+  auto enqueue = [&](int ring, int id) {
+    int n = 0;  // lane r < WF_RINGS: how many lanes of this wave enqueue to ring r
+#pragma unroll
+    for (int r = 0; r < WF_RINGS; ++r) {
+      const int c = __popcll(__ballot(ring == r));
+      n = lane == r ? c : n;
+    }
     int base = 0;
-    if (lane == leader) base = __hip_atomic_fetch_add(&ctl[WF_CTL_TAIL(r)], __popcll(m), __ATOMIC_RELAXED, WF_WG);
-    base = __shfl(base, leader);
-    if (want) {
-      uint16_t* const s = ringSlots + r * RCAP + ((base + __popcll(m & laneBelow)) & RMASK);
+    if (lane < WF_RINGS && n > 0) base = __hip_atomic_fetch_add(&ctl[WF_CTL_TAIL(lane)], n, __ATOMIC_RELAXED, WF_WG);
+    int myBase = 0;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int r = 0; r < WF_RINGS; ++r) {
+      const int b = __builtin_amdgcn_readlane(base, r);
+      const unsigned long long m = __ballot(ring == r);
+      if (ring == r) {
+        myBase = b;
+        mine = m;
+      }
+    }
+    if (ring >= 0) {
+      uint16_t* const s = ringSlots + ring * RCAP + ringPos((uint32_t)(myBase + __popcll(mine & laneBelow)));
       int spins = 0;
       while (__hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG) != 0) {
         if (++spins > WF_SPIN_LIMIT) {
@@ -152,9 +182,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   auto claim = [&](int r, unsigned long long takers, int want, int atLeast, int& id) -> int {
     int h = 0, k = 0;
     if (lane == 0) {
-      h = __hip_atomic_load(&ctl[WF_CTL_HEAD(r)], __ATOMIC_RELAXED, WF_WG);
+      const unsigned long long th = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&ctl[WF_CTL_TAIL(r)]), __ATOMIC_RELAXED, WF_WG);
+      int t = (int)th;
+      h = (int)(th >> 32);
       for (;;) {
-        const int t = __hip_atomic_load(&ctl[WF_CTL_TAIL(r)], __ATOMIC_RELAXED, WF_WG);
         const int avail = (int)((uint32_t)t - (uint32_t)h);
         k = avail < want ? avail : want;
         if (k < atLeast || k <= 0) {
@@ -163,7 +194,8 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         }
         int expected = h;
         if (__hip_atomic_compare_exchange_strong(&ctl[WF_CTL_HEAD(r)], &expected, h + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, WF_WG)) break;
-        h = expected;
+        h = expected;  // another wave claimed meanwhile: the tail can only have grown
+        t = __hip_atomic_load(&ctl[WF_CTL_TAIL(r)], __ATOMIC_RELAXED, WF_WG);
       }
     }
     h = __builtin_amdgcn_readfirstlane(h);
@@ -171,7 +203,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     id = -1;
     const int rank = __popcll(takers & laneBelow);
     if (((takers >> lane) & 1ull) && rank < k) {
-      uint16_t* const s = ringSlots + r * RCAP + ((h + rank) & RMASK);
+      uint16_t* const s = ringSlots + r * RCAP + ringPos((uint32_t)(h + rank));
       int v, spins = 0;
       while ((v = __hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG)) == 0) {
         if (++spins > WF_SPIN_LIMIT) {
@@ -218,63 +250,122 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     w = 0;
     cur = localRef(sc.world[0]);
   };
+  // the next camera ray of a context (main.cpp:204-216): A, B, C of its line
+  auto cameraRayInto = [&](int at, uint32_t pxy, int s) {
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    Pcg rng;
+    rng.key(seedMixed, (uint32_t)(py * a.imageWidth + px), (uint32_t)s);
+    const float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
+    const float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
+    Ray r;
+    cameraRay(a.cam, u, v, rng, r);
+    bufStore4(rsPool, at, make_float4(r.o.x, r.o.y, r.o.z, r.time));
+    bufStore4(rsPool, at + 16, make_float4(r.d.x, r.d.y, r.d.z, 0.0f));
+    u32x4 Cn;
+    Cn.x = (uint32_t)rng.state;
+    Cn.y = (uint32_t)(rng.state >> 32);
+    Cn.z = 0;
+    Cn.w = 0;  // depth 0, in flight (a miss unless a hit step says otherwise)
+    __builtin_amdgcn_raw_buffer_store_b128(Cn, rsPool, at + 32, 0, 0);
+  };
 
   int idleTrips = 0;  // consecutive decisions that found nothing to do (bounded: see "Termination" above)
+  uint32_t tick = 0;
+  unsigned long long pCyc[WF_PROF_KINDS], pRuns[WF_PROF_KINDS], pLanes[WF_PROF_KINDS], pSched = 0;
+  // what the scheduling decisions that looked at the rings saw, summed: decisions, lanes at nodes / at primitives /
+  // finished / idle, READY fill, fill of the fullest served ring, RESTART fill
+  unsigned long long pSaw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < WF_PROF_KINDS; ++k) pCyc[k] = pRuns[k] = pLanes[k] = 0;
+  const unsigned long long pStart = PROFILE ? clock64() : 0;
+  unsigned long long pT = pStart;  // the clock at the end of the last step: what follows until the next step begins is scheduling
+  auto prof = [&](int kind, int lanes) {  // closes the step that began at pT
+    if (PROFILE) {
+      const unsigned long long now = clock64();
+      pCyc[kind] += now - pT;
+      pRuns[kind]++;
+      pLanes[kind] += lanes;
+      pT = now;
+    }
+  };
   for (;;) {
     // ---- scheduling decision
     const unsigned long long mN = __ballot(atNode()), mP = __ballot(atPrim()), mF = __ballot(cur == DONE && path >= 0),
                              mI = __ballot(path < 0);
     const int nN = __popcll(mN), nP = __popcll(mP), nF = __popcll(mF), nI = __popcll(mI);
-    // ring fill (every lane reads the same words: broadcast reads)
-    int avail[WF_RINGS];
+    const int free = nF + nI;
+    int pick, serveAtLeast = 64, bestRing = WF_RING_RESTART;
+    // The rings are looked at when this wave has lanes to refill, nothing to traverse, or every fourth decision: with
+    // sixteen waves deciding, a full batch is still seen within a fraction of the time it took to fill.
+    if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) {
+      unsigned long long* cw = reinterpret_cast<unsigned long long*>(ctl + 16);
+      // relaxed 64-bit atomic loads: fresh values every time, two words per LDS read, broadcast to the wave
+      const unsigned long long w0 = __hip_atomic_load(cw + 0, __ATOMIC_RELAXED, WF_WG), w1 = __hip_atomic_load(cw + 1, __ATOMIC_RELAXED, WF_WG),
+                               w2 = __hip_atomic_load(cw + 2, __ATOMIC_RELAXED, WF_WG), w3 = __hip_atomic_load(cw + 3, __ATOMIC_RELAXED, WF_WG),
+                               w4 = __hip_atomic_load(cw + 4, __ATOMIC_RELAXED, WF_WG), w5 = __hip_atomic_load(cw + 5, __ATOMIC_RELAXED, WF_WG),
+                               w6 = __hip_atomic_load(cw + 6, __ATOMIC_RELAXED, WF_WG);
+      // words 16 + 2r / 17 + 2r tail / head of ring r, 28 live, 29 abort
+      if ((int)(w6 >> 32) != 0) break;  // abort
+      auto fill = [](unsigned long long th) { return (int)((uint32_t)th - (uint32_t)(th >> 32)); };
+      const int readyAvail = __builtin_amdgcn_readfirstlane(fill(w0));
+      const int av[5] = {fill(w1), fill(w2), fill(w3), fill(w4), fill(w5)};  // RESTART, HIT 0..2, NEWITEM
+      int bestAvail = av[0];
 #pragma unroll
-    for (int r = 0; r < WF_RINGS; ++r)
-      avail[r] = (int)((uint32_t)__hip_atomic_load(&ctl[WF_CTL_TAIL(r)], __ATOMIC_RELAXED, WF_WG) -
-                       (uint32_t)__hip_atomic_load(&ctl[WF_CTL_HEAD(r)], __ATOMIC_RELAXED, WF_WG));
-    if (__hip_atomic_load(&ctl[WF_CTL_ABORT], __ATOMIC_RELAXED, WF_WG) != 0) break;
-    int bestRing = WF_RING_RESTART, bestAvail = avail[WF_RING_RESTART];
-#pragma unroll
-    for (int r = WF_RING_HIT; r < WF_RINGS; ++r)
-      if (avail[r] > bestAvail) {
-        bestAvail = avail[r];
-        bestRing = r;
+      for (int r = 1; r < 5; ++r)
+        if (av[r] > bestAvail) {
+          bestAvail = av[r];
+          bestRing = WF_RING_RESTART + r;
+        }
+      bestRing = __builtin_amdgcn_readfirstlane(bestRing);
+      bestAvail = __builtin_amdgcn_readfirstlane(bestAvail);
+      // what a swap would move: finished walks out, READY contexts into the lanes without one
+      const int swapGain = nF + (readyAvail < free ? readyAvail : free);
+      if (bestAvail >= 64)
+        pick = W_SERVE;  // a full batch is always worth a step (and feeds READY)
+      else if (swapGain >= a.wfSwapMin)
+        pick = W_SWAP;
+      else if (nP >= a.primMin || (nN == 0 && nP > 0))
+        pick = W_PRIM;
+      else if (nN > 0)
+        pick = W_NODE;
+      else if (swapGain > 0)
+        pick = W_SWAP;
+      else if (bestAvail > 0) {
+        pick = W_SERVE;  // nothing to traverse here and nothing READY: serve what there is
+        serveAtLeast = 1;
+      } else {
+        if (__builtin_amdgcn_readfirstlane((int)w6) <= 0) break;  // every context has retired
+        if (++idleTrips > WF_SPIN_LIMIT) {
+          raiseAbort();
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        prof(7, 0);
+        continue;
       }
-    bestRing = __builtin_amdgcn_readfirstlane(bestRing);
-    bestAvail = __builtin_amdgcn_readfirstlane(bestAvail);
-    const int readyAvail = __builtin_amdgcn_readfirstlane(avail[WF_RING_READY]);
-    const bool canSwap = nF > 0 || (nI > 0 && readyAvail > 0);
-    int pick, serveAtLeast = 64;
-    if (nF + nI >= a.wfSwapBig && canSwap)
-      pick = W_SWAP;  // half the wave has nothing to traverse
-    else if (bestAvail >= 64)
-      pick = W_SERVE;  // a full batch is always worth a step
-    else if (nF + nI >= a.wfSwapMin && canSwap)
-      pick = W_SWAP;
-    else if (nP >= a.primMin || (nN == 0 && nP > 0))
-      pick = W_PRIM;
-    else if (nN > 0)
-      pick = W_NODE;
-    else if (canSwap)
-      pick = W_SWAP;
-    else if (bestAvail > 0) {
-      pick = W_SERVE;  // nothing to traverse here: serve what there is
-      serveAtLeast = 1;
+      idleTrips = 0;
+      if (PROFILE) {
+        pSaw[0]++; pSaw[1] += nN; pSaw[2] += nP; pSaw[3] += nF; pSaw[4] += nI;
+        (void)readyAvail;
+      }
     } else {
-      if (__hip_atomic_load(&ctl[WF_CTL_LIVE], __ATOMIC_RELAXED, WF_WG) <= 0) break;  // every context has retired
-      if (++idleTrips > WF_SPIN_LIMIT) {
-        raiseAbort();
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-      continue;
+      pick = nP >= a.primMin ? W_PRIM : W_NODE;  // nN + nP > 0 here; a wave with only a few lanes at primitives and none at nodes:
+      if (nN == 0) pick = W_PRIM;
     }
-    idleTrips = 0;
+    if (PROFILE) {
+      const unsigned long long now = clock64();
+      pSched += now - pT;
+      pT = now;
+    }
 
     int nNodes = nN;
     if (pick == W_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit (as srt_render_kernel)
       for (int round = 0; round < SRT_PRIM_ROUNDS; ++round) {
         if (round > 0 && __popcll(__ballot(atPrim())) < a.primAgainMin) break;
+        if (PROFILE) {
+          pRuns[1]++;
+          pLanes[1] += __popcll(__ballot(atPrim()));
+        }
         if (atPrim()) {
           const int pr = ~cur;
           float t;
@@ -300,6 +391,11 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         }
       }
       nNodes = __popcll(__ballot(atNode()));
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pCyc[1] += now - pT;
+        pT = now;
+      }
       if (nNodes >= a.fuseMin) pick = W_NODE;
     }
 
@@ -308,6 +404,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       const int keep = (nNodes * a.keepEighths) >> 3;
       int budget = a.nodeBurst;
       auto nodeVisit = [&]() {
+        if (PROFILE) {
+          pRuns[0]++;
+          pLanes[0] += __popcll(__ballot(atNode()));
+        }
         if (atNode()) {
           const float4 n0 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5));
           const float4 n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
@@ -327,46 +427,73 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
         budget -= SRT_NODE_UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pCyc[0] += now - pT;
+        pT = now;
+      }
     } else if (pick == W_SWAP) {
-      // ------------------------------------------------ finished walks out, READY contexts in
+      // ------------------------------------------------ finished walks out, READY contexts in.  The new rays' lines are
+      // asked for first and arrive while the finished walks are handed over (LDS traffic only).
       const bool fin = cur == DONE && path >= 0;
       const bool hit = fin && hitRef != DONE;
-      int cls = -1;
-      if (hit) {
-        // what the hit step needs beyond the ray: t and the primitive; the class of its material picks the ring.
-        // (A miss stores nothing: the context already says "in flight, nothing hit".)
-        bufStore1(rsPool, (path << 7) + 28, __float_as_uint(closest));
-        bufStore1(rsPool, (path << 7) + 40, (uint32_t)hitRef);
-        cls = (int)__builtin_amdgcn_raw_buffer_load_b8(rsClass, ~hitRef, 0, 0);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      enqueue(WF_RING_RESTART, fin && !hit, path);
-#pragma unroll
-      for (int c = 0; c < WF_CLASSES; ++c) enqueue(WF_RING_HIT + c, hit && cls == c, path);
-      if (fin) path = -1;
-      const unsigned long long mNeed = __ballot(path < 0);
+      const unsigned long long mNeed = __ballot(path < 0 || fin);
       int id = -1;
+      // the class of the hit primitive's material picks the ring: asked for first, it is there when the claim is done
+      int cls = 0;
+      if (hit) cls = (int)__builtin_amdgcn_raw_buffer_load_b8(rsClass, ~hitRef, 0, 0);
+      const unsigned long long q0 = PROFILE ? clock64() : 0;
       if (mNeed != 0) claim(WF_RING_READY, mNeed, __popcll(mNeed), 1, id);
+      const unsigned long long q1 = PROFILE ? clock64() : 0;
+      float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f), B = A;
       if (id >= 0) {
-        const float4 A = bufLoad4(rsPool, id << 7), B = bufLoad4(rsPool, (id << 7) + 16);
+        A = bufLoad4(rsPool, id << 7);
+        B = bufLoad4(rsPool, (id << 7) + 16);
+      }
+      if (hit) {
+        // what the hit step needs beyond the ray: t and the primitive (LDS).  A miss leaves nothing: the context already
+        // says "in flight, nothing hit".
+        __hip_atomic_store(&hitT[path], closest, __ATOMIC_RELAXED, WF_WG);
+        __hip_atomic_store(&hitPrim[path], (uint16_t)hitRef, __ATOMIC_RELAXED, WF_WG);
+      }
+      asm volatile("" ::: "memory");  // the ring slot is written after them (one wave's LDS operations execute in order)
+      enqueue(!fin ? -1 : (hit ? WF_RING_HIT + cls : WF_RING_RESTART), path);
+      if (fin) {
+        path = -1;
+        hitRef = DONE;
+      }
+      const unsigned long long q2 = PROFILE ? clock64() : 0;
+      if (id >= 0) {
         ray.o = mk(A.x, A.y, A.z);
         ray.d = mk(B.x, B.y, B.z);
         ray.time = A.w;
         path = id;
         startTraversal();
       }
+      if (PROFILE) {
+        const unsigned long long q3 = clock64();
+        pSaw[5] += q1 - q0;  // swap: claim
+        pSaw[6] += q2 - q1;  // swap: hand-over of the finished walks
+        pSaw[7] += q3 - q2;  // swap: new rays arrive, set-up
+      }
+      prof(2, __popcll(__ballot(fin)) + __popcll(__ballot(id >= 0)));
     } else if (pick == W_SERVE) {
       // ------------------------------------------------ serve a ring: 64 contexts in the same state
       int id;
       const int k = claim(bestRing, ~0ull, 64, serveAtLeast, id);
-      if (k == 0) continue;  // another wave took them
+      if (k == 0) {  // another wave took them
+        prof(8, 0);
+        continue;
+      }
       const int at = id << 7;
-      if (bestRing >= WF_RING_HIT) {
+      if (bestRing >= WF_RING_HIT && bestRing < WF_RING_HIT + WF_CLASSES) {
         // ---------------------------- rayColor's hit branch (main.cpp:42-51): one path vertex per lane
         bool toReady = false, toRestart = false;
         if (id >= 0) {
           const float4 A = bufLoad4(rsPool, at), B = bufLoad4(rsPool, at + 16);
           const u32x4 C = __builtin_amdgcn_raw_buffer_load_b128(rsPool, at + 32, 0, 0);
+          const float tHit = __hip_atomic_load(&hitT[id], __ATOMIC_RELAXED, WF_WG);
+          const int pr = ~(int)(int16_t)__hip_atomic_load(&hitPrim[id], __ATOMIC_RELAXED, WF_WG);
           Ray rIn;
           rIn.o = mk(A.x, A.y, A.z);
           rIn.d = mk(B.x, B.y, B.z);
@@ -375,11 +502,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           rng.state = (uint64_t)C.x | ((uint64_t)C.y << 32);
           int depth = (int)(C.w & 0xffu);
           Record rec;
-          const int pr = ~(int)C.z;
           if (pr & 1)
-            sphereRecord(sc, pr >> 1, rIn, B.w, rec, false);
+            sphereRecord(sc, pr >> 1, rIn, tHit, rec, false);
           else
-            triRecord(sc, pr >> 1, rIn, B.w, rec, false);
+            triRecord(sc, pr >> 1, rIn, tHit, rec, false);
           V3 att, emitted;
           Ray next;
           uint32_t fetches = 0;
@@ -405,7 +531,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           u32x4 Cn;
           Cn.x = (uint32_t)rng.state;
           Cn.y = (uint32_t)(rng.state >> 32);
-          Cn.z = (uint32_t)DONE;
+          Cn.z = 0;
           if (done) {
             // the path ends here: its terminal radiance takes the (dead) direction's place
             bufStore4(rsPool, at + 16, make_float4(terminal.x, terminal.y, terminal.z, 0.0f));
@@ -420,184 +546,177 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           __builtin_amdgcn_raw_buffer_store_b128(Cn, rsPool, at + 32, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        enqueue(WF_RING_READY, toReady, id);
-        enqueue(WF_RING_RESTART, toRestart, id);
-      } else {
-        // ---------------------------- path restart: miss / path end (main.cpp:39-40,49-51), pixel sum (main.cpp:217),
-        // next work item, next camera ray (main.cpp:204-216)
-        bool toReady = false, again = false, retired = false;
-        float4 D = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        int outIndex = -1, s = 0, sEnd = 0;
-        uint32_t pxy = 0;
+        enqueue(toReady ? WF_RING_READY : (toRestart ? WF_RING_RESTART : -1), id);
+        prof(3 + bestRing - WF_RING_HIT, k);
+      } else if (bestRing == WF_RING_RESTART) {
+        // ---------------------------- a sample is in: miss / path end (main.cpp:39-40,49-51), pixel sum (main.cpp:217),
+        // next camera ray of the item (main.cpp:204-216) -- or, after the item's last sample, its sum goes out and the
+        // context goes for the next item
+        bool toReady = false, toNewItem = false;
         if (id >= 0) {
+          // the whole line at once: one round trip
+          const float4 B = bufLoad4(rsPool, at + 16);
           const u32x4 C = __builtin_amdgcn_raw_buffer_load_b128(rsPool, at + 32, 0, 0);
+          float4 D = bufLoad4(rsPool, at + 48);
           const u32x4 E = __builtin_amdgcn_raw_buffer_load_b128(rsPool, at + 64, 0, 0);
-          D = bufLoad4(rsPool, at + 48);
-          outIndex = (int)E.x;
-          s = (int)E.y;
-          sEnd = (int)E.z;
-          pxy = E.w;
+          const float4 F = bufLoad4(rsPool, at + 80), G = bufLoad4(rsPool, at + 96), H = bufLoad4(rsPool, at + 112);
+          const int outIndex = (int)E.x, sEnd = (int)E.z;
+          int s = (int)E.y;
           const int depth = (int)(C.w & 0xffu), pend = (int)((C.w >> 8) & 0xffu);
-          if (pend != WF_PEND_NONE) {
-            V3 L = background;  // main.cpp:39-40 (pend 0: the ray went out of the scene)
-            if (pend == WF_PEND_TERMINAL) {
-              const float4 T = bufLoad4(rsPool, at + 16);
-              L = mk(T.x, T.y, T.z);
-            }
-            // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
-            for (int j = depth - 1; j >= 0; --j) {
-              float ax, ay, az;
-              if (j < 4) {
-                ax = __uint_as_float(bufLoad1(rsPool, at + 80 + 12 * j));
-                ay = __uint_as_float(bufLoad1(rsPool, at + 84 + 12 * j));
-                az = __uint_as_float(bufLoad1(rsPool, at + 88 + 12 * j));
-              } else {
-                const int slot = (3 * (j - 4) * POOL + id) * 4;
-                ax = __uint_as_float(bufLoad1(rsAttHi, slot));
-                ay = __uint_as_float(bufLoad1(rsAttHi, slot + POOL * 4));
-                az = __uint_as_float(bufLoad1(rsAttHi, slot + POOL * 8));
-              }
-              L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
-            }
-            D.x += L.x;  // main.cpp:217
-            D.y += L.y;
-            D.z += L.z;
-            s++;
+          V3 L = background;  // main.cpp:39-40 (the ray went out of the scene)
+          if (pend == WF_PEND_TERMINAL) L = mk(B.x, B.y, B.z);
+          // unwind the recursion: emitted + newColor * attenuation, innermost first (main.cpp:49-51)
+          const float lv[12] = {F.x, F.y, F.z, F.w, G.x, G.y, G.z, G.w, H.x, H.y, H.z, H.w};
+          for (int j = depth - 1; j >= 4; --j) {
+            const int slot = (3 * (j - 4) * POOL + id) * 4;
+            const float ax = __uint_as_float(bufLoad1(rsAttHi, slot)), ay = __uint_as_float(bufLoad1(rsAttHi, slot + POOL * 4)),
+                        az = __uint_as_float(bufLoad1(rsAttHi, slot + POOL * 8));
+            L = mk(0.0f + L.x * ax, 0.0f + L.y * ay, 0.0f + L.z * az);
           }
-        }
-        // work item finished (or none yet): write it, pull the next one with one atomic per wave
-        const bool needItem = id >= 0 && s >= sEnd;
-        const unsigned long long mF2 = __ballot(needItem);
-        if (mF2 != 0) {
-          if (needItem && outIndex >= 0) {
-            if (a.fix)
-              commitFixed(a.fix + outIndex, mk(D.x, D.y, D.z));
-            else
-              a.out[outIndex] = D;
-          }
-          const int leader = __ffsll((long long)mF2) - 1;
-          const int q = __builtin_amdgcn_readfirstlane(*waveQueue);
-          bool gotItem = false, alive = true;
-          int idx = 0;
-          if (q >= 0) {
-            int base = 0;
-            if (lane == leader) base = atomicAdd(a.queue + 16 * q, __popcll(mF2));
-            base = __shfl(base, leader);
-            idx = base + __popcll(mF2 & laneBelow);
-            const int qEnd = queueEnd(q);
-            gotItem = needItem && idx < qEnd;
-            if (base + __popcll(mF2) > qEnd) {
-              // drained: the leader looks at every queue's counter, the wave moves to the fullest one (own XCD first)
-              int nq = -1;
-              if (lane == leader) {
-                int bestLeft = 0;
-                bool bestOwn = false;
-                for (int kq = 0; kq < a.numQueues; ++kq) {
-                  const int left = queueEnd(kq) - __hip_atomic_load(a.queue + 16 * kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  const bool own = ((kq ^ qHome) & 7) == 0;
-                  if (left > 0 && ((own && !bestOwn) || (own == bestOwn && left > bestLeft))) {
-                    bestLeft = left;
-                    bestOwn = own;
-                    nq = kq;
-                  }
-                }
-                *waveQueue = nq;
-              }
-              nq = __shfl(nq, leader);
-              if (!gotItem && nq < 0) alive = false;
-            }
-          } else {
-            alive = false;
-          }
-          if (needItem) {
-            outIndex = -1;
-            D = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (!gotItem) {
-              s = sEnd = 0;
-              retired = !alive;  // nothing left anywhere: this context is done
-              again = alive;     // an empty item: pull again from the wave's new queue
-            } else {
-              // idx -> (local tile, chunk, pixel of the tile), without integer divisions (as srt_render_kernel)
-              const int group = idx >> 6, ln = idx & 63;
-              int u = (int)((float)group * a.rcpUnitGroups);
-              int inUnit = group - u * a.unitGroups;
-              if (inUnit < 0) {
-                u--;
-                inUnit += a.unitGroups;
-              } else if (inUnit >= a.unitGroups) {
-                u++;
-                inUnit -= a.unitGroups;
-              }
-              int tileInUnit = (int)((float)inUnit * a.rcpChunks);
-              int chunk = inUnit - tileInUnit * a.sppChunks;
-              if (chunk < 0) {
-                tileInUnit--;
-                chunk += a.sppChunks;
-              } else if (chunk >= a.sppChunks) {
-                tileInUnit++;
-                chunk -= a.sppChunks;
-              }
-              const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
-              const int tile = a.tileFirst + localTile * a.tileStride;
-              const uint32_t txy = a.tileXY[tile < a.numTiles ? tile : 0];
-              const int px = (int)(txy & 0xffffu) * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
-              const int py = (int)(txy >> 16) * SRT_TILE_H + (ln >> 3);
-              pxy = (uint32_t)px | ((uint32_t)py << 16);
-              const int s0 = a.sampleFirst + chunk * a.sppBase + min(chunk, a.sppRem);
-              const int s1 = s0 + a.sppBase + (chunk < a.sppRem ? 1 : 0);
-              D.w = (float)(s1 - s0);
-              const bool valid = localTile < a.numLocalTiles && tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && a.maxBounce > 0;
-              s = s0;
-              sEnd = valid ? s1 : s0;
-              outIndex = localTile < a.numLocalTiles ? chunk * a.chunkStride + localTile * SRT_TILE_PIXELS + ln : -1;
-              again = !valid;  // an item with nothing to trace (outside the image, or no bounces): its zero sum is written next time round
-            }
-          }
-        }
-        if (id >= 0) {
-          u32x4 Cn;
-          Cn.z = (uint32_t)DONE;
-          Cn.w = (uint32_t)(WF_PEND_NONE << 8);
-          Cn.x = Cn.y = 0;
-          if (!retired && s < sEnd) {
-            const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
-            Pcg rng;
-            rng.key(seedMixed, (uint32_t)(py * a.imageWidth + px), (uint32_t)s);
-            const float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
-            const float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
-            Ray r;
-            cameraRay(a.cam, u, v, rng, r);
-            bufStore4(rsPool, at, make_float4(r.o.x, r.o.y, r.o.z, r.time));
-            bufStore4(rsPool, at + 16, make_float4(r.d.x, r.d.y, r.d.z, 0.0f));
-            Cn.x = (uint32_t)rng.state;
-            Cn.y = (uint32_t)(rng.state >> 32);
-            Cn.w = 0;  // depth 0, in flight
+#pragma unroll
+          for (int j = 3; j >= 0; --j)
+            if (j < depth) L = mk(0.0f + L.x * lv[3 * j], 0.0f + L.y * lv[3 * j + 1], 0.0f + L.z * lv[3 * j + 2]);
+          D.x += L.x;  // main.cpp:217
+          D.y += L.y;
+          D.z += L.z;
+          s++;
+          if (s < sEnd) {
+            bufStore4(rsPool, at + 48, D);
+            bufStore1(rsPool, at + 68, (uint32_t)s);
+            cameraRayInto(at, E.w, s);
             toReady = true;
-            again = false;
+          } else {
+            // the item is complete: its partial sum goes out (exact chunk sums: srt_path.h)
+            if (outIndex >= 0) {
+              if (a.fix)
+                commitFixed(a.fix + outIndex, mk(D.x, D.y, D.z), a.fixLimit);
+              else
+                a.out[outIndex] = D;
+            }
+            toNewItem = true;
           }
-          __builtin_amdgcn_raw_buffer_store_b128(Cn, rsPool, at + 32, 0, 0);
-          bufStore4(rsPool, at + 48, D);
-          u32x4 En;
-          En.x = (uint32_t)outIndex;
-          En.y = (uint32_t)s;
-          En.z = (uint32_t)sEnd;
-          En.w = pxy;
-          __builtin_amdgcn_raw_buffer_store_b128(En, rsPool, at + 64, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        enqueue(WF_RING_READY, toReady, id);
-        enqueue(WF_RING_RESTART, again && !toReady, id);
+        enqueue(toReady ? WF_RING_READY : (toNewItem ? WF_RING_NEWITEM : -1), id);
+        prof(6, k);
+      } else {
+        // ---------------------------- the next work item for every context here, with one atomic for the wave
+        // (main.cpp:200-203: the pixel loop; work queues as in srt_render_kernel), and its first camera ray
+        const bool need = id >= 0;
+        const unsigned long long mF2 = __ballot(need);
+        const int q = __builtin_amdgcn_readfirstlane(*waveQueue);
+        bool gotItem = false, alive = true;
+        int idx = 0;
+        if (q >= 0) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(a.queue + 16 * q, __popcll(mF2));
+          base = __builtin_amdgcn_readfirstlane(base);
+          idx = base + __popcll(mF2 & laneBelow);
+          const int qEnd = queueEnd(q);
+          gotItem = need && idx < qEnd;
+          if (base + __popcll(mF2) > qEnd) {
+            // drained: lane 0 looks at every queue's counter, the wave moves to the fullest one (own XCD first)
+            int nq = -1;
+            if (lane == 0) {
+              int bestLeft = 0;
+              bool bestOwn = false;
+              for (int kq = 0; kq < a.numQueues; ++kq) {
+                const int left = queueEnd(kq) - __hip_atomic_load(a.queue + 16 * kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool own = ((kq ^ qHome) & 7) == 0;
+                if (left > 0 && ((own && !bestOwn) || (own == bestOwn && left > bestLeft))) {
+                  bestLeft = left;
+                  bestOwn = own;
+                  nq = kq;
+                }
+              }
+              *waveQueue = nq;
+            }
+            nq = __builtin_amdgcn_readfirstlane(nq);
+            if (nq < 0) alive = false;
+          }
+        } else {
+          alive = false;
+        }
+        bool toReady = false, again = false, retired = false;
+        if (need) {
+          if (!gotItem) {
+            retired = !alive;  // nothing left anywhere: this context is done
+            again = alive;     // the wave's queue ran dry under it: pull again from the new one
+          } else {
+            // idx -> (local tile, chunk, pixel of the tile), without integer divisions (as srt_render_kernel)
+            const int group = idx >> 6, ln = idx & 63;
+            int u = (int)((float)group * a.rcpUnitGroups);
+            int inUnit = group - u * a.unitGroups;
+            if (inUnit < 0) {
+              u--;
+              inUnit += a.unitGroups;
+            } else if (inUnit >= a.unitGroups) {
+              u++;
+              inUnit -= a.unitGroups;
+            }
+            int tileInUnit = (int)((float)inUnit * a.rcpChunks);
+            int chunk = inUnit - tileInUnit * a.sppChunks;
+            if (chunk < 0) {
+              tileInUnit--;
+              chunk += a.sppChunks;
+            } else if (chunk >= a.sppChunks) {
+              tileInUnit++;
+              chunk -= a.sppChunks;
+            }
+            const int localTile = (q + u * a.numQueues) * a.unitTiles + tileInUnit;  // may pad past numLocalTiles
+            const int tile = a.tileFirst + localTile * a.tileStride;
+            const uint32_t txy = a.tileXY[tile < a.numTiles ? tile : 0];
+            const int px = (int)(txy & 0xffffu) * SRT_TILE_W + (ln & (SRT_TILE_W - 1));
+            const int py = (int)(txy >> 16) * SRT_TILE_H + (ln >> 3);
+            const uint32_t pxy = (uint32_t)px | ((uint32_t)py << 16);
+            const int s0 = a.sampleFirst + chunk * a.sppBase + min(chunk, a.sppRem);
+            const int s1 = s0 + a.sppBase + (chunk < a.sppRem ? 1 : 0);
+            // maxBounce <= 0: rayColor returns black before tracing anything (main.cpp:36-37)
+            const bool valid = localTile < a.numLocalTiles && tile < a.numTiles && px < a.imageWidth && py < a.imageHeight && a.maxBounce > 0;
+            const int outIndex = localTile < a.numLocalTiles ? chunk * a.chunkStride + localTile * SRT_TILE_PIXELS + ln : -1;
+            const float4 D = make_float4(0.0f, 0.0f, 0.0f, (float)(s1 - s0));
+            if (valid) {
+              bufStore4(rsPool, at + 48, D);
+              u32x4 En;
+              En.x = (uint32_t)outIndex;
+              En.y = (uint32_t)s0;
+              En.z = (uint32_t)s1;
+              En.w = pxy;
+              __builtin_amdgcn_raw_buffer_store_b128(En, rsPool, at + 64, 0, 0);
+              cameraRayInto(at, pxy, s0);
+              toReady = true;
+            } else {
+              // an item with nothing to trace (a pixel outside the image, or no bounces): its zero sum is written at once
+              if (outIndex >= 0 && !a.fix) a.out[outIndex] = D;
+              again = true;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        enqueue(toReady ? WF_RING_READY : (again ? WF_RING_NEWITEM : -1), id);
         const unsigned long long mR = __ballot(retired);
         if (mR != 0 && lane == __ffsll((long long)mR) - 1) __hip_atomic_fetch_sub(&ctl[WF_CTL_LIVE], __popcll(mR), __ATOMIC_RELAXED, WF_WG);
+        prof(9, k);
       }
     }
+  }
+  if (PROFILE && a.stats && lane == 0) {
+    for (int k = 0; k < WF_PROF_KINDS; ++k) {
+      atomicAdd(&a.stats[32 + k], pCyc[k]);
+      atomicAdd(&a.stats[32 + WF_PROF_KINDS + k], pRuns[k]);
+      atomicAdd(&a.stats[32 + 2 * WF_PROF_KINDS + k], pLanes[k]);
+    }
+    atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS], pSched);
+    atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 1], (unsigned long long)(clock64() - pStart));
+    for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 2 + k], pSaw[k]);
   }
 }
 
 extern "C" {
-int srt_launch_render_wf(const RenderArgs* a, int grid, size_t ldsBytes, hipStream_t stream) {
+int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream) {
   typedef void (*Kernel)(const RenderArgs);
-  const Kernel k = a->scene.numWorld == 1 ? srt_render_wf_kernel<true> : srt_render_wf_kernel<false>;
+  const Kernel k = profile ? srt_render_wf_kernel<false, true>
+                           : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false> : srt_render_wf_kernel<false, false>);
   if (ldsBytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return (int)e;

@@ -21,12 +21,12 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
-           "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks",
+           "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks", "srtPlanSppChunks",
            "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays",
            "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtGetLaunchInfo", "srtRenderAov"]
+TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtGetWfProfile", "srtGetLaunchInfo", "srtRenderAov"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -48,6 +48,8 @@ lib.srtNumLocalTiles.argtypes = [C.c_int32, C.c_int32, C.c_int32]
 lib.srtNumLocalTiles.restype = C.c_int32
 lib.srtDefaultSppChunks.argtypes = [C.c_int32]
 lib.srtDefaultSppChunks.restype = C.c_int32
+lib.srtPlanSppChunks.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+lib.srtPlanSppChunks.restype = C.c_int32
 lib.srtRenderTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtResolveTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _vp, _vp]
 lib.srtRenderImage.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
@@ -61,6 +63,7 @@ lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtGetShadeProfile.argtypes = [_vp, _vp]
+lib.srtGetWfProfile.argtypes = [_vp, _vp]
 lib.srtGetLaunchInfo.argtypes = [_vp, _vp]
 lib.srtRenderAov.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), C.c_int32, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
@@ -98,6 +101,11 @@ def num_local_tiles(w, h, stride):
 
 def default_spp_chunks(spp):
     return int(lib.srtDefaultSppChunks(spp))
+
+
+def plan_spp_chunks(width, height, spp, spp_chunks=0):
+    """The chunk count a render of this size uses (-1: an explicit count that does not fit); include/srt_hip.h."""
+    return int(lib.srtPlanSppChunks(width, height, spp, spp_chunks))
 
 
 def _reset_generator_for(scene_builder):
@@ -257,6 +265,18 @@ class Context:
         out = np.zeros(10, np.uint64)
         self._check(lib.srtGetShadeProfile(self.h, out.ctypes.data))
         return [int(x) for x in out]
+
+    def wf_profile(self):
+        """Step profile of the last path-pool launch with tunable wf_profile = 1 (include/srt_hip_test.h)."""
+        out = np.zeros(40, np.uint64)
+        self._check(lib.srtGetWfProfile(self.h, out.ctypes.data))
+        kinds = ["node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "idle", "lost_claim", "new_item"]
+        prof = {k: {"clocks": int(out[i]), "runs": int(out[10 + i]), "lanes": int(out[20 + i])} for i, k in enumerate(kinds)}
+        prof["sched_clocks"], prof["total_clocks"] = int(out[30]), int(out[31])
+        n = max(1, int(out[32]))
+        prof["decisions"] = int(out[32])
+        prof["mean_seen"] = {k: float(out[33 + i]) / n for i, k in enumerate(["at_node", "at_prim", "finished", "idle", "ready_fill", "fullest_ring", "restart_fill"])}
+        return prof
 
     def launch_info(self):
         """The most recent render launch (include/srt_hip_test.h).  lds_tree_mode: 0 node records through the L1,

@@ -563,7 +563,7 @@ def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camer
     import torch
     W, H = 320, 180
     saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront")}
-    assert saved["lds_tree"] >= 1 and saved["wavefront"] == 1  # the defaults
+    assert saved["lds_tree"] >= 1 and saved["wavefront"] >= 1  # the defaults: node-count thresholds
     for name, spp, mb in (("masterchief", 8, 4), ("spheres", 8, 8), ("iron", 4, 4)):
         ctx.upload_scene(srt.scenes.SCENES[name]())
         ctx.set_camera(camera)

@@ -155,6 +155,24 @@ def test_default_chunk_plan(dev):
         assert 1 <= dev.default_spp_chunks(spp) <= spp
 
 
+def test_chunk_plan_is_the_default_at_the_baseline_sizes(dev):
+    """srtPlanSppChunks: the plan a render uses is srtDefaultSppChunks at every BASELINE size (a clamp by
+    64 x 1024 phantom tiles used to cut 720p to 419 and 1080p to 342 chunks), explicit counts are honoured up to the
+    32-bit work-item index and refused beyond, and the plan never depends on anything but image size and sample count."""
+    for (w, h, spp) in ((426, 240, 64), (1280, 720, 1024), (1280, 720, 5000), (1920, 1080, 8192), (3840, 2160, 8192)):
+        want = dev.default_spp_chunks(spp)
+        got = dev.plan_spp_chunks(w, h, spp, 0)
+        if w * h <= 1920 * 1080:
+            assert got == want, (w, h, spp, got, want)
+        else:
+            assert 1 <= got <= want
+    assert dev.plan_spp_chunks(1280, 720, 5000, 625) == 625 and dev.plan_spp_chunks(1280, 720, 5000, 628) == 628
+    assert dev.plan_spp_chunks(1280, 720, 5000, 1250) == 1250
+    assert dev.plan_spp_chunks(1280, 720, 5000, 2500) == -1      # 14400 tiles x 64 x 2500 slots > 2^31
+    assert dev.plan_spp_chunks(1280, 720, 8, 9) == -1 and dev.plan_spp_chunks(0, 720, 8, 0) == -1
+    assert dev.plan_spp_chunks(1280, 720, 5000, 1) == 1
+
+
 def test_sphere_field_scene_is_deterministic(srt, oracle, dev):
     """scene_sphere_field consumes the process-global generator from its reset state: same scene every
     time, and the product's host BVH builder and the oracle agree on its tree (moving spheres' boxes)."""

@@ -21,7 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = c
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "srt_render_kernel" not in k: continue
+        if "srt_render_" not in k: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 with open(out + "/pmc_summary.csv", "w") as fo:
     fo.write("kernel,counter,dispatches,sum,per_dispatch\n")

@@ -13,11 +13,11 @@ scenes = sys.argv[1:] or ["spheres", "masterchief", "iron"]
 for name in scenes:
     ctx.upload_scene(srt.scenes.SCENES[name]())
     ctx.set_camera(cam)
-    mb = 8 if name == "spheres" else 4
+    mb = 8 if name in ("spheres", "sphere_field") else 4
     for (W, H, spp, chunks) in ((64, 36, 2, 1), (160, 90, 8, 0), (426, 240, 16, 0), (1280, 720, 64, 0)):
         out = {}
         for wf in (0, 1):
-            ctx.set_tunable("wavefront", wf)
+            ctx.set_tunable("wavefront", wf)  # 1: every tree that fits, however small
             local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
             p = abi.default_render_params(W, H, spp, mb, seed=3, spp_chunks=chunks)
             ctx.render_tiles(p, local.data_ptr(), None)

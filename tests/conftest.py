@@ -77,7 +77,8 @@ def render_counted(ctx, p, node_path):
         return ctx.render_image(p)
     p.countStats = 0
     acc, rgba = ctx.render_image(p)
-    assert ctx.launch_info()["wavefront"], ctx.launch_info()
+    info = ctx.launch_info()
+    assert info["wavefront"] or not info["lds_tree"], info  # a world without a tree (or with one that does not fit) has no LDS-resident form
     p.countStats = 1
     ctx.render_image(p)
     return acc, rgba

@@ -302,7 +302,10 @@ int srtResolveTiles(SrtContext* ctx, const SrtRenderParams* p, const void* dGath
  *                       dGathered = float4[numRanks][numLocalTiles*64] (DEVICE), others NULL.
  *                       Asynchronous on `stream`.  With one rank it degenerates to a device copy.
  *   srtRenderImageRanks the blocking main.cpp:182-227 form across the ranks (collective): render own tiles,
- *                       the one gather, rank 0 resolves into its caller-owned HOST buffers
+ *                       the one gather, rank 0 resolves into its caller-owned HOST buffers.  Before the gather the
+ *                       ranks agree (a 4-byte all-reduce) that every one of them rendered: if one failed, ALL return
+ *                       non-zero together instead of some waiting in the gather.  A rank that is lost altogether
+ *                       leaves its peers in a collective: they then need srtCommDestroy (ncclCommAbort semantics).
  *   srtCommDestroy      also done by srtDestroy */
 #define SRT_COMM_ID_BYTES 128
 int srtCommGetUniqueId(void* id128);

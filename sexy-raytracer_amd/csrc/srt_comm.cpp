@@ -111,24 +111,50 @@ int srtRenderImageRanks(SrtContext* ctx, const SrtRenderParams* pIn, float* hAcc
   const size_t nPix = (size_t)p.imageWidth * p.imageHeight;
   const size_t localBytes = (size_t)srtNumLocalTiles(p.imageWidth, p.imageHeight, numRanks) * SRT_TILE_PIXELS * sizeof(float4);
   void *dLocal = nullptr, *dGathered = nullptr, *dRgba = nullptr, *dAcc = nullptr;
+  int32_t* dAgree = nullptr;
   int rc = 1;
   do {
-    if (hipMalloc(&dLocal, localBytes) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); break; }
-    if (rank == 0) {
-      if (hipMalloc(&dGathered, localBytes * numRanks) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); break; }
-      if (hRgba && hipMalloc(&dRgba, nPix * 4) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); break; }
-      if (hAccum && hipMalloc(&dAcc, nPix * sizeof(float4)) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); break; }
+    // Everything that can fail on ONE rank happens before the gather, and the ranks agree on it first: a rank that
+    // broke out here while the others entered ncclGather would leave them waiting for ever.  The agreement is a
+    // 4-byte all-reduce (minimum of the ranks' status); only a rank that cannot even allocate those 4 bytes leaves
+    // without taking part -- its peers then need ncclCommAbort (srtCommDestroy), as after any lost rank.
+    if (numRanks > 1 && hipMalloc((void**)&dAgree, sizeof(int32_t)) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc (4 bytes)"); break; }
+    int32_t ok = 1;
+    if (hipMalloc(&dLocal, localBytes) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); ok = 0; }
+    if (ok && rank == 0) {
+      if (hipMalloc(&dGathered, localBytes * numRanks) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); ok = 0; }
+      if (ok && hRgba && hipMalloc(&dRgba, nPix * 4) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); ok = 0; }
+      if (ok && hAccum && hipMalloc(&dAcc, nPix * sizeof(float4)) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: hipMalloc"); ok = 0; }
     }
-    if (srtRenderTiles(ctx, &p, dLocal, nullptr)) break;
+    if (ok && srtRenderTiles(ctx, &p, dLocal, nullptr)) ok = 0;
+    if (ok && hipDeviceSynchronize() != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: render kernel failed"); ok = 0; }
+    if (numRanks > 1) {
+      ncclComm_t comm = static_cast<ncclComm_t>(*srtCtxCommSlot(ctx));
+      int32_t agreed = 0;
+      if (!comm) { srtCtxFail(ctx, "srtRenderImageRanks: no communicator (srtCommInit)"); break; }
+      if (hipMemcpy(dAgree, &ok, sizeof ok, hipMemcpyHostToDevice) != hipSuccess ||
+          ncclAllReduce(dAgree, dAgree, 1, ncclInt32, ncclMin, comm, nullptr) != ncclSuccess ||
+          hipMemcpy(&agreed, dAgree, sizeof agreed, hipMemcpyDeviceToHost) != hipSuccess) {
+        srtCtxFail(ctx, "srtRenderImageRanks: the ranks could not agree on the render's status");
+        break;
+      }
+      if (!agreed) {
+        if (ok) srtCtxFail(ctx, "srtRenderImageRanks: another rank failed before the gather");
+        break;
+      }
+    } else if (!ok) {
+      break;
+    }
     if (srtGatherTiles(ctx, &p, dLocal, dGathered, nullptr)) break;
     if (rank == 0 && srtResolveTiles(ctx, &p, dGathered, dRgba, dAcc, nullptr)) break;
-    if (hipDeviceSynchronize() != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: kernel or gather failed"); break; }
+    if (hipDeviceSynchronize() != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: gather or resolve failed"); break; }
     if (rank == 0) {
       if (hRgba && hipMemcpy(hRgba, dRgba, nPix * 4, hipMemcpyDeviceToHost) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: copy rgba"); break; }
       if (hAccum && hipMemcpy(hAccum, dAcc, nPix * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) { srtCtxFail(ctx, "srtRenderImageRanks: copy accum"); break; }
     }
     rc = 0;
   } while (0);
+  if (dAgree) (void)hipFree(dAgree);
   for (void* q : {dLocal, dGathered, dRgba, dAcc})
     if (q) (void)hipFree(q);
   return rc;

@@ -228,6 +228,65 @@ def test_render_720p_headline_frame_vs_oracle(ctx, oracle, abi, scenes, camera, 
     assert info["lds_tree"] == (node_path != "l1_nodes") and info["wavefront"] == (node_path == "wavefront")
 
 
+FULL_SIZE_CONFIGS = {  # BASELINE.json configs[1..4] at their own size
+    "C2_spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8, (200, 420, 640)),
+    "C3_iron_720p_5000spp": ("iron", 1280, 720, 5000, 4, (330, 470, 600)),
+    "C4_masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4, (250, 400, 560)),
+    "C5_masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4, (480, 840)),
+}
+
+
+@pytest.mark.parametrize("config", sorted(FULL_SIZE_CONFIGS))
+def test_full_sample_count_rows_vs_oracle(ctx, dev, oracle, abi, scenes, camera, config):
+    """Every BASELINE frame at ITS OWN size and sample count through the production kernel with the library's default
+    chunk plan (the launch bench.py times), two or three pixel rows of it against the oracle rendered at the same
+    sample count with the same counter-RNG keys (main.cpp:200-227 at the sizes of main.cpp:175-180).  The oracle keeps
+    the reference's single running float sum, the kernel adds ~8-sample chunks exactly: <= 2e-5 relative apart, except
+    where one of a pixel's thousands of samples took another texel or checker square (device libm vs glibc, one ulp).
+    C5 also runs the atomic form of the exact chunk sum (its 21 GB of chunk slots exceed the scratch budget) and must be
+    bit-identical for the 8-way tile split."""
+    import torch
+    name, W, H, spp, mb, rows = FULL_SIZE_CONFIGS[config]
+    sb = scenes[name]
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    p = abi.default_render_params(W, H, spp, mb, seed=11, spp_chunks=0)
+    acc, rgba = ctx.render_image(p)
+    info = ctx.launch_info()
+    assert info["lds_tree"] and info["wavefront"] == (name == "masterchief"), info  # the default kernels for these scenes
+    assert dev.plan_spp_chunks(W, H, spp, 0) == dev.default_spp_chunks(spp)
+    osc = oracle.OracleScene(sb)
+    threads = min(16, os.cpu_count() or 8)
+    for y in rows:
+        want, want_rgba, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=threads, rows=(y, y + 1), want_stats=False)
+        a, b = acc[y, :, :3].astype(np.float64), want[y, :, :3].astype(np.float64)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), (config, y)
+        nan = np.isnan(b)
+        err = np.where(nan, 0.0, np.abs(a - b))
+        scale = np.where(nan, 1.0, np.maximum(np.abs(b), 1e-3))
+        close = (err <= 2e-5 * scale).all(axis=-1)
+        assert close.mean() >= 0.99, (config, y, close.mean(), (err / scale).max())
+        assert (err <= 2e-3 * scale).all(), (config, y, (err / scale).max())
+        assert np.array_equal(acc[y, :, 3], want[y, :, 3])  # every sample counted
+        d = np.abs(rgba[y].astype(int) - want_rgba[y].astype(int))
+        assert d.max() <= 1, (config, y, d.max())
+    if config.startswith("C5"):
+        # the 8-way interleaved tile split (one rank's share after the other on this GPU) against the 1-way frame
+        one = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+        ctx.render_tiles(p, one.data_ptr(), None)
+        torch.cuda.synchronize()
+        parts = []
+        for r in range(8):
+            local = torch.zeros((dev.num_local_tiles(W, H, 8), 64, 4), dtype=torch.float32, device="cuda")
+            pr = abi.default_render_params(W, H, spp, mb, seed=11, spp_chunks=0, tile_first=r, tile_stride=8)
+            ctx.render_tiles(pr, local.data_ptr(), None)
+            parts.append(local)
+        torch.cuda.synchronize()
+        ctx.last_kernel_ms()
+        split = torch.stack(parts, 1).reshape(-1, 64, 4)[: one.shape[0]]  # local tile l of rank r is tile position l * 8 + r
+        assert torch.equal(split.view(torch.int32), one.view(torch.int32))
+
+
 def test_sphere_field_vs_oracle(ctx, oracle, abi, srt, camera, node_path):
     """the 22x22 sphere field main.cpp:92-122 keeps commented out -- 480-odd small spheres,
     most of them moving (sphere.h:47-52), fuzzy metals and glass, in one bvhNode: same tree as the oracle,

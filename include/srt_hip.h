@@ -321,6 +321,14 @@ int srtRenderImage(SrtContext* ctx, const SrtRenderParams* p, float* hAccum, uin
 /* Fixed-ray-set parity entry: world.hit(r, tMin, tMax, rec) for n rays. HOST pointers. */
 int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, int32_t traversal);
 
+/* material::scatter + material::emitted (material.h:15-21; texture::value through a light's emitted, texture.h:13-16) for
+ * n (incoming ray, hit record) pairs, evaluated by the render kernels' own shading function.  hits[i].material indexes
+ * the uploaded scene's materials; p, normal, tangent, bitangent, uv, t, frontFace are read as the reference's hitRecord
+ * fields.  Random draws come from the counter RNG keyed (seed, i, 0) -- the reference draws from its process-global
+ * generator.  out13 per entry: attenuation[3], scattered direction[3], scattered origin[3], scatter's bool (0 / 1),
+ * emitted[3].  HOST pointers; blocking. */
+int srtScatterRays(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
+
 /* Duration of the most recent srtRenderTiles kernel, from HIP events recorded
  * on its stream (synchronises on the stop event). */
 int srtLastKernelMs(SrtContext* ctx, float* ms);

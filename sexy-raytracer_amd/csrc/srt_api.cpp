@@ -1373,7 +1373,12 @@ int srtTraceRays(SrtContext* ctx, const SrtRay* rays, int64_t n, SrtHit* hits, i
 }
 
 // test entry: material::scatter known answers through the kernel's own shade()
+int srtScatterRays(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13);
 int srtScatterTest(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13) {
+  return srtScatterRays(ctx, rays, hits, n, seed, out13);  // the test hook's old name
+}
+
+int srtScatterRays(SrtContext* ctx, const SrtRay* rays, const SrtHit* hits, int32_t n, uint64_t seed, float* out13) {
   if (!ctx || !rays || !hits || !out13 || n < 1) return 1;
   if (!ctx->haveScene) return fail(ctx, "scatter: no scene uploaded");
   HIP_OK(ctx, hipSetDevice(ctx->device));

@@ -22,7 +22,7 @@ lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",
            "srtUploadScene", "srtSetCamera", "srtBuildBvh", "srtGetBvh", "srtGetBvhDepth", "srtNumTiles", "srtNumLocalTiles", "srtDefaultSppChunks", "srtPlanSppChunks",
-           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays",
+           "srtRenderTiles", "srtResolveTiles", "srtRenderImage", "srtTraceRays", "srtScatterRays",
            "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
@@ -60,6 +60,7 @@ lib.srtGatherTiles.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp, _v
 lib.srtRenderImageRanks.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), _vp, _vp]
 lib.srtCommDestroy.argtypes = [_vp]
 lib.srtScatterTest.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
+lib.srtScatterRays.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_uint64, _vp]
 lib.srtSetTunable.argtypes = [_vp, C.c_char_p, C.c_int32]
 lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtGetShadeProfile.argtypes = [_vp, _vp]

@@ -1,14 +1,26 @@
-// material.h -- host mirror of the reference's material classes (material.h:15-154): same class
-// names and constructor signatures.  scatter()/emitted() run on the device (srt_kernels.hip shade()).
+// material.h -- host mirror of the reference's material classes (material.h:15-154): same class names and constructor
+// signatures.  scatter() / emitted() keep the reference's signatures (material.h:17-20) and are answered by the device
+// (csrc/srt_path.h shade(), through srtScatterRays: shade_device.h); there is no host copy of the BRDF arithmetic.
 #ifndef SRT_HOST_MATERIAL_H
 #define SRT_HOST_MATERIAL_H
 
 #include "texture.h"
 
+struct hitRecord;
+class ray;
+struct srtShadeSession;
+
 class material {
  public:
   virtual ~material() {}
   virtual int populate(sceneFlattener& f) const = 0;  // appends an SrtMaterialIn, returns its id
+  // material.h:17 and :18-20.  One device round trip per call; the random draws of a scatter come from the counter RNG,
+  // keyed by the number of scatter() calls this material has answered (the reference draws from its global generator).
+  virtual bool scatter(const ray& rIn, const hitRecord& record, color3f& attenuation, ray& scatterRay) const;
+  virtual color3f emitted(float u, float v, const vec3f& p) const;
+
+ private:
+  mutable shared_ptr<srtShadeSession> shadeSession_;
 };
 
 class pbrMetallicRoughness : public material {  // material.h:23-85
@@ -113,5 +125,7 @@ inline int sceneFlattener::materialId(const shared_ptr<material>& m) {
   materialPtrs[id] = m;
   return id;
 }
+
+#include "shade_device.h"
 
 #endif

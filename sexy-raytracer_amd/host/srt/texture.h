@@ -1,6 +1,6 @@
-// texture.h -- host mirror of the reference's texture classes (texture.h:13-153).
-// value(u,v,p) is evaluated on the device (csrc/srt_kernels.hip texValue); here a texture only
-// knows how to describe itself to the flattener.
+// texture.h -- host mirror of the reference's texture classes (texture.h:13-153).  A texture knows how to describe
+// itself to the flattener; value(u, v, p) keeps the reference's signature (texture.h:15) and is answered by the device
+// (csrc/srt_path.h texValue, through srtScatterRays: shade_device.h) -- there is no host copy of the lookup arithmetic.
 #ifndef SRT_HOST_TEXTURE_H
 #define SRT_HOST_TEXTURE_H
 
@@ -10,10 +10,17 @@
 #include "flatten.h"
 #include "png.h"
 
+struct srtShadeSession;
+
 class texture {
  public:
   virtual ~texture() {}
   virtual int populate(sceneFlattener& f) const = 0;  // appends an SrtTextureIn, returns its id
+  // texture.h:15.  One device round trip per call (shade_device.h).
+  virtual color3f value(float u, float v, const vec3f& p) const;
+
+ private:
+  mutable shared_ptr<srtShadeSession> shadeSession_;
 };
 
 class solidColor : public texture {  // texture.h:18-32

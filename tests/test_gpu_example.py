@@ -115,3 +115,41 @@ def test_cpp_world_hit_on_the_host_classes(ctx, abi, srt):
         assert np.array_equal(vals.view(np.uint32), ref.view(np.uint32)), (k, vals, ref)
         assert int(f[8]) == int(want["frontFace"][k]) and int(f[9]) == mat_of_prim[int(want["prim"][k])]
     assert out[35] == "ball hit" and float.fromhex(out[36].split()[1]) == 2.0
+
+    # ---- material::scatter / material::emitted / texture::value on the host classes (material.h:15-21, texture.h:13-16):
+    # the same program went on to call rec.matPtr->scatter(r, rec, attenuation, scattered) for every hit of the grid.
+    # Each material answers from a device context of its own and keys the counter RNG by its own call count; the same
+    # (ray, hit record, key) through srtScatterRays on the Python-built scene must give the same bits.
+    lines = out[37:]
+    scat = [l.split() for l in lines if l.startswith("scatter ")]
+    hit_idx = [k for k in range(35) if want["prim"][k] >= 0]
+    assert len(scat) == len(hit_idx) >= 20
+    calls = {}
+    for f, k in zip(scat, hit_idx):
+        m = int(want["material"][k])
+        key = calls.get(m, 0)
+        calls[m] = key + 1
+        ref = ctx.scatter_test(rays[k:k + 1], want[k:k + 1], key)[0]
+        got = np.array([float.fromhex(x) for x in f[2:12]], np.float32)
+        assert int(f[1]) == int(ref[9]), (k, f, ref)
+        assert np.array_equal(got[0:3].view(np.uint32), ref[0:3].view(np.uint32)), (k, "attenuation", got, ref)
+        assert np.array_equal(got[3:6].view(np.uint32), ref[3:6].view(np.uint32)), (k, "direction")
+        assert np.array_equal(got[6:9].view(np.uint32), ref[6:9].view(np.uint32)) and got[9] == np.float32(0.25)
+    assert len(calls) >= 3  # ground, diffuse or glass, mirror were all hit
+    em = [float.fromhex(x) for x in next(l for l in lines if l.startswith("emitted ")).split()[1:]]
+    assert em == [4.0, 3.0, 2.0, 0.0, 0.0, 0.0]  # diffuseLight::emitted (material.h:144-150) / material::emitted (:18-20)
+    # checker::value (texture.h:42-48): sign of sin(10x) sin(10y) sin(10z) picks odd / even, colours times 255
+    chk = [[float.fromhex(x) for x in l.split()[1:]] for l in lines if l.startswith("checker ")]
+    assert len(chk) == 6
+    for k, c in enumerate(chk):
+        p = np.float32([0.11 + 0.37 * k, 0.05 - 0.21 * k, 0.4 + 0.13 * k])
+        sines = np.sin(np.float32(10.0) * p).prod()
+        col = np.float32([0.9, 0.9, 0.9] if sines < 0 else [0.2, 0.3, 0.1]) * np.float32(255.0)
+        assert np.array_equal(np.float32(c), col), (k, c, col, sines)
+    # imagePNG::value (texture.h:129-148): nearest texel, v flipped, bytes as floats; the 3 x 2 image hit_probe wrote
+    img = (10 + 13 * np.arange(18)).astype(np.uint8).reshape(2, 3, 3)
+    tex = [[float.fromhex(x) for x in l.split()[1:]] for l in lines if l.startswith("texel ")]
+    assert len(tex) == 4
+    for (u, v), c in zip(((0.0, 0.0), (0.4, 0.9), (0.99, 0.2), (1.0, 1.0)), tex):
+        i, j = min(int(u * 3), 2), min(int((1.0 - v) * 2), 1)
+        assert c == [float(x) for x in img[j, i]], (u, v, c, img[j, i])

@@ -152,6 +152,40 @@ def test_exact_chunk_sum_paths_agree(ctx, dev, abi, srt, camera):
         ctx.set_tunable("chunk_scratch_mb", budget)
 
 
+def test_chunk_sums_cannot_wrap_on_fireflies(ctx, abi, camera):
+    """a few chunk sums near 2^26 used to wrap the 64-bit fixed-point pixel sum negative (a black pixel where
+    the reference's float sum gives white).  A partial sum of 2^26 / (chunk count rounded up to a power of two) or more
+    now counts as infinite.  A light of radiance 3e7 seen directly: with 64 chunks (limit 2^20) and with 4 chunks (limit
+    2^24) every chunk sum over the light is beyond the limit: the scratch path, the atomic path
+    and the single float sum must all resolve to the same white pixels, the two exact paths bit-identical, and nothing
+    anywhere may come out negative or NaN."""
+    sb = abi.SceneBuilder()
+    sb.add_sphere((0.0, 2.5, 0.0), 1.5, sb.light((3.0e7, 2.0e7, 4.0e7)))
+    sb.add_sphere((0.0, -1000.0, 0.0), 1000.0, sb.pbr(albedo=(0.8, 0.8, 0.8, 1.0), roughness=0.5))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    ctx.upload_scene(sb)
+    ctx.set_camera(camera)
+    budget = ctx.get_tunable("chunk_scratch_mb")
+    try:
+        single_acc, single = ctx.render_image(abi.default_render_params(160, 90, 64, 4, seed=23, spp_chunks=1))
+        assert (single[..., :3] == 255).all(axis=-1).mean() > 0.02  # the light is in the picture
+        for chunks in (64, 4):
+            out = {}
+            for mb in (budget, 0):
+                ctx.set_tunable("chunk_scratch_mb", mb)
+                out[mb] = ctx.render_image(abi.default_render_params(160, 90, 64, 4, seed=23, spp_chunks=chunks))
+            (acc_s, rgba_s), (acc_a, rgba_a) = out[budget], out[0]
+            assert np.array_equal(acc_s.view(np.uint32), acc_a.view(np.uint32)), chunks
+            assert np.array_equal(rgba_s, rgba_a) and np.array_equal(rgba_s, single), chunks
+            assert not np.isnan(acc_s).any() and (acc_s[..., :3] >= 0).all(), chunks
+            lit = (single[..., :3] == 255).all(axis=-1)
+            assert np.isinf(acc_s[lit][:, :3]).any(), chunks  # beyond the limit: counted as infinite, not wrapped
+            finite = np.isfinite(acc_s[..., :3]).all(axis=-1)
+            assert np.allclose(acc_s[finite][:, :3], single_acc[finite][:, :3], rtol=2e-5, atol=1e-6)
+    finally:
+        ctx.set_tunable("chunk_scratch_mb", budget)
+
+
 def test_ragged_and_tiny_images(ctx, oracle, abi, srt, camera):
     sb = srt.scenes.scene_spheres()
     ctx.upload_scene(sb)

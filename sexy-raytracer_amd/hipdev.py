@@ -18,6 +18,15 @@ if not os.path.exists(LIB_PATH):
     raise ImportError("HIP extension not built: %s is missing (run __graft_entry__.build() or "
                       "`make -C sexy-raytracer_amd/csrc`)" % LIB_PATH)
 
+# PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's, which this library is
+# linked against).  One process gets ONE of them -- whichever is loaded first -- and torch does not find the GPU through
+# /opt/rocm's copy ("No HIP GPUs are available").  The tests and bench.py take their device buffers from torch, so torch
+# goes first when it is there; the library runs on either copy.  (C / C++ callers never meet this.)
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostRandomFloat", "srtHostRandomReset",

@@ -228,25 +228,45 @@ def test_render_720p_headline_frame_vs_oracle(ctx, oracle, abi, scenes, camera, 
     assert info["lds_tree"] == (node_path != "l1_nodes") and info["wavefront"] == (node_path == "wavefront")
 
 
-FULL_SIZE_CONFIGS = {  # BASELINE.json configs[1..4] at their own size
-    "C2_spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8, (200, 420, 640)),
-    "C3_iron_720p_5000spp": ("iron", 1280, 720, 5000, 4, (330, 470, 600)),
-    "C4_masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4, (250, 400, 560)),
-    "C5_masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4, (480, 840)),
+FULL_SIZE_CONFIGS = {  # BASELINE.json configs[1..4] at their own size; two adjacent pixel rows each
+    "C2_spheres_720p_1024spp": ("spheres", 1280, 720, 1024, 8, 420),
+    "C3_iron_720p_5000spp": ("iron", 1280, 720, 5000, 4, 470),
+    "C4_masterchief_720p_5000spp": ("masterchief", 1280, 720, 5000, 4, 400),
+    "C5_masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4, 640),
 }
+
+
+def _oracle_rows_in_chunks(oracle, osc, abi, camera, W, H, spp, mb, seed, chunks, y0, y1, threads):
+    """The oracle's render of rows [y0, y1) with the kernel's chunk plan: chunk c holds samples
+    [c * base + min(c, rem), ...) (base = spp // chunks, rem = spp % chunks: srt_api.cpp), each chunk a float running sum
+    in sample order (main.cpp:217), the chunk sums added exactly (float64 holds the sum of a few hundred float32 chunk
+    sums of this size without rounding) and rounded to float32 once -- what the exact chunk sums of the kernel compute."""
+    base, rem = spp // chunks, spp % chunks
+    total = np.zeros((y1 - y0, W, 3), np.float64)
+    count = np.zeros((y1 - y0, W), np.float64)
+    for c in range(chunks):
+        s0 = c * base + min(c, rem)
+        n = base + (1 if c < rem else 0)
+        p = abi.default_render_params(W, H, n, mb, seed=seed, sample_first=s0)
+        part, _, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=threads, rows=(y0, y1), want_rgba=False, want_stats=False)
+        total += part[y0:y1, :, :3].astype(np.float64)
+        count += part[y0:y1, :, 3]
+    with np.errstate(over="ignore", invalid="ignore"):
+        return total.astype(np.float32), count
 
 
 @pytest.mark.parametrize("config", sorted(FULL_SIZE_CONFIGS))
 def test_full_sample_count_rows_vs_oracle(ctx, dev, oracle, abi, scenes, camera, config):
     """Every BASELINE frame at ITS OWN size and sample count through the production kernel with the library's default
-    chunk plan (the launch bench.py times), two or three pixel rows of it against the oracle rendered at the same
-    sample count with the same counter-RNG keys (main.cpp:200-227 at the sizes of main.cpp:175-180).  The oracle keeps
-    the reference's single running float sum, the kernel adds ~8-sample chunks exactly: <= 2e-5 relative apart, except
-    where one of a pixel's thousands of samples took another texel or checker square (device libm vs glibc, one ulp).
-    C5 also runs the atomic form of the exact chunk sum (its 21 GB of chunk slots exceed the scratch budget) and must be
-    bit-identical for the 8-way tile split."""
+    chunk plan (the launch bench.py times), two pixel rows of it against the oracle rendered at the same sample count
+    with the same counter-RNG keys and the same chunk plan (main.cpp:200-227 at the sizes of main.cpp:175-180): the
+    pixel sums must be the same BITS, except where one of a pixel's thousands of samples took another texel or checker
+    square (device libm vs glibc, one ulp: the residual every render test carries).  C5 also runs the atomic form of the
+    exact chunk sum (its 21 GB of chunk slots exceed the scratch budget) and must be bit-identical for the 8-way tile
+    split.  (Against the reference's SINGLE running float sum the same rows differ by up to 1e-4 relative at 5000 spp:
+    that is the running sum's own rounding drift -- adding 0.53 five thousand times -- not the kernel's.)"""
     import torch
-    name, W, H, spp, mb, rows = FULL_SIZE_CONFIGS[config]
+    name, W, H, spp, mb, y = FULL_SIZE_CONFIGS[config]
     sb = scenes[name]
     ctx.upload_scene(sb)
     ctx.set_camera(camera)
@@ -254,22 +274,22 @@ def test_full_sample_count_rows_vs_oracle(ctx, dev, oracle, abi, scenes, camera,
     acc, rgba = ctx.render_image(p)
     info = ctx.launch_info()
     assert info["lds_tree"] and info["wavefront"] == (name == "masterchief"), info  # the default kernels for these scenes
-    assert dev.plan_spp_chunks(W, H, spp, 0) == dev.default_spp_chunks(spp)
+    chunks = dev.plan_spp_chunks(W, H, spp, 0)
+    assert chunks == dev.default_spp_chunks(spp)
     osc = oracle.OracleScene(sb)
-    threads = min(16, os.cpu_count() or 8)
-    for y in rows:
-        want, want_rgba, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=threads, rows=(y, y + 1), want_stats=False)
-        a, b = acc[y, :, :3].astype(np.float64), want[y, :, :3].astype(np.float64)
-        assert np.array_equal(np.isnan(a), np.isnan(b)), (config, y)
-        nan = np.isnan(b)
-        err = np.where(nan, 0.0, np.abs(a - b))
-        scale = np.where(nan, 1.0, np.maximum(np.abs(b), 1e-3))
-        close = (err <= 2e-5 * scale).all(axis=-1)
-        assert close.mean() >= 0.99, (config, y, close.mean(), (err / scale).max())
-        assert (err <= 2e-3 * scale).all(), (config, y, (err / scale).max())
-        assert np.array_equal(acc[y, :, 3], want[y, :, 3])  # every sample counted
-        d = np.abs(rgba[y].astype(int) - want_rgba[y].astype(int))
-        assert d.max() <= 1, (config, y, d.max())
+    want, count = _oracle_rows_in_chunks(oracle, osc, abi, camera, W, H, spp, mb, 11, chunks, y, y + 2, min(16, os.cpu_count() or 8))
+    got = acc[y:y + 2, :, :3]
+    assert np.array_equal(np.isnan(got), np.isnan(want)), config
+    bit = (_bits(got) == _bits(want)).all(axis=-1)
+    assert bit.mean() >= 0.98, (config, bit.mean())
+    nan = np.isnan(want)
+    err = np.where(nan, 0.0, np.abs(got.astype(np.float64) - want.astype(np.float64)))
+    scale = np.where(nan, 1.0, np.maximum(np.abs(want.astype(np.float64)), 1e-3))
+    assert (err <= 2e-3 * scale).all(), (config, (err / scale).max())
+    assert np.array_equal(acc[y:y + 2, :, 3], count)  # every sample counted
+    want_rgba = oracle.resolve(np.concatenate([want, count[..., None].astype(np.float32)], axis=-1), spp)
+    d = np.abs(rgba[y:y + 2].astype(int) - want_rgba.astype(int))
+    assert d.max() <= 1, (config, d.max())
     if config.startswith("C5"):
         # the 8-way interleaved tile split (one rank's share after the other on this GPU) against the 1-way frame
         one = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")

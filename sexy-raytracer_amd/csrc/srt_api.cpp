@@ -34,6 +34,7 @@ int srt_lbvh_build(const DevScene* sc, const int32_t* dRefs, int n, float time0,
 int srt_ploc_build(const DevScene* sc, const int32_t* dRefs, int n, float time0, float time1, float4* outNodes,
                    uint8_t* outAxis, int base, int radius, int* depthOut);
 int srt_pair_nodes(const DevScene* sc, float time0, float time1, float4* out);
+int srt_wide_nodes(const float4* nodes2, int numNodes, float4* out);
 int srt_launch_scatter(const DevScene* sc, const SrtRay* rays, const SrtHit* hits, float* out, uint64_t seed, int n,
                        hipStream_t stream);
 }
@@ -232,6 +233,7 @@ struct Tunables {
   int keepEighths;
   int ldsTree;
   int wavefront, wfPool, wfSwapMin, wfSwapBig, wfProfile;
+  int wideNodes, attGlobal;
 };
 
 struct SrtContext {
@@ -347,14 +349,21 @@ const TunableName kTunables[] = {
     // many nodes (traversal-heavy frames gain, shading-heavy ones with tiny trees lose: profiles/r03/wavefront.txt); 0 = never
     {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 2048},
     {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 2048},       // path contexts per workgroup (1024 lanes traverse)
-    {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 16},
+    {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 32},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
-    {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
+    {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},
+    // closest-hit traversal: 128-byte records with four boxes (1, read at srtUploadScene) instead of the 64-byte two-box
+    // records (0).  Measured, not faster: the same bytes in half as many, twice as large random requests, at 2 instead
+    // of 3 workgroups per CU (three pending references per level) -- profiles/r03/wide_nodes.txt.  Off.
+    {"wide_nodes", "SRT_WIDE_NODES", &Tunables::wideNodes, 0},
+    // closest-hit traversal of trees with at least this many nodes: attenuation stacks in global memory (4 instead of 3
+    // workgroups per CU); 0 = never.  +3 % at 4 M triangles, -5 % at 10 M (same file).  Off.
+    {"att_global", "SRT_ATT_GLOBAL", &Tunables::attGlobal, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
 };
 
-size_t ldsBytesFor(const SrtContext* ctx, int maxBounce) {
+size_t ldsBytesFor(const SrtContext* ctx, int maxBounce, int stackDepth, bool attGlobal = false) {
   // per-thread stacks plus one word of queue state per wave (srt_render_kernel)
-  return (size_t)(ctx->scene.stackDepth + 2 + 3 * maxBounce + 3) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
+  return (size_t)(stackDepth + 2 + (attGlobal ? 0 : 3 * maxBounce + 3)) * 256 * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 
 }  // namespace
@@ -939,6 +948,18 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
     s.nodes2 = static_cast<const float4*>(b2.p);
     int rc2 = srt_pair_nodes(&s, t0, t1, static_cast<float4*>(b2.p));
     if (rc2) return fail(ctx, "pairing the node records failed: %s", hipGetErrorString((hipError_t)rc2));
+    // ... and the 128-byte records with four boxes, for trees big enough to be fetched from HBM (and small enough for
+    // index * 128 to stay a 31-bit byte offset)
+    if (ctx->tun.wideNodes > 0 && s.numNodes >= 2 && s.numNodes < (1 << 24)) {
+      DeviceBuffer b4;
+      b4.bytes = (size_t)s.numNodes * 128;
+      HIP_OK(ctx, hipMalloc(&b4.p, b4.bytes));
+      ctx->sceneBuffers.push_back(b4);
+      rc2 = srt_wide_nodes(s.nodes2, s.numNodes, static_cast<float4*>(b4.p));
+      if (rc2) return fail(ctx, "building the four-box records failed: %s", hipGetErrorString((hipError_t)rc2));
+      s.nodes4 = static_cast<const float4*>(b4.p);
+      s.wideStackDepth = 3 * ((ctx->bvhDepth + 1) / 2 + 1) + 1;
+    }
   }
   const bool lbvhOk = lbvhCertificate;
   if (nodes.size() / 2 > (size_t)SRT_MAX_NODES) return fail(ctx, "scene: %zu BVH nodes exceed the %d the device references can address", nodes.size() / 2, SRT_MAX_NODES);
@@ -1214,7 +1235,20 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   // small BASELINE scenes; the headline scene's tree leaves no room (mode 1: they live in global memory)
   const size_t attBytes = (size_t)(3 * p->maxBounce + 3) * 1024 * sizeof(float);
   const int ldsTreeMode = !ldsTree ? 0 : (ldsTreeBytes + attBytes <= 160 * 1024 ? 2 : 1);
-  const size_t lds = ldsTreeMode == 2 ? ldsTreeBytes + attBytes : ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce);
+  // closest-hit traversal over the four-box records: its stack holds up to three pending references per wide level; a
+  // tree too deep for that beside the attenuation stacks (64 KB per workgroup at most: two workgroups per CU) walks the
+  // two-box records instead
+  const bool attGlobal256 = !ldsTree && p->traversal == SRT_TRAVERSE_CLOSEST && ctx->tun.attGlobal > 0 && ctx->scene.numNodes >= ctx->tun.attGlobal;
+  if (p->traversal == SRT_TRAVERSE_CLOSEST && a.scene.nodes4) {
+    const int need = std::max(a.scene.stackDepth, a.scene.wideStackDepth);
+    if (ldsBytesFor(ctx, p->maxBounce, need, attGlobal256) <= 80 * 1024)
+      a.scene.stackDepth = need;
+    else
+      a.scene.nodes4 = nullptr;
+  } else {
+    a.scene.nodes4 = nullptr;
+  }
+  const size_t lds = ldsTreeMode == 2 ? ldsTreeBytes + attBytes : ldsTree ? ldsTreeBytes : ldsBytesFor(ctx, p->maxBounce, a.scene.stackDepth, attGlobal256);
   if (lds > 160 * 1024) return fail(ctx, "render: BVH depth %d needs %zu B of LDS per workgroup", ctx->scene.stackDepth, lds);
   // The path-pool kernel (srt_wavefront.hip) serves what the LDS-resident tree serves, when its rings fit behind the
   // tree: one 1024-thread workgroup per CU, wfPool contexts each.  The counting variant stays with srt_render_kernel.
@@ -1271,8 +1305,8 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
-  } else if (ldsTreeMode == 1) {
-    if (ensure(ctx->attScratch, (size_t)(3 * p->maxBounce + 3) * grid * 1024 * sizeof(float))) return 1;
+  } else if (ldsTreeMode == 1 || attGlobal256) {
+    if (ensure(ctx->attScratch, (size_t)(3 * p->maxBounce + 3) * grid * (ldsTree ? 1024 : 256) * sizeof(float))) return 1;
     a.attScratch = static_cast<float*>(ctx->attScratch.p);
   }
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));

@@ -61,6 +61,11 @@ struct DevScene {
   // (index * 64); built from `nodes` on the device after upload (srt_lbvh.hip, srt_pair_nodes).  One 64-byte request
   // per visit tests two boxes; the 32-byte records use half of every request they cause.
   const float4* nodes2;
+  // SRT_TRAVERSE_CLOSEST, wide form: one 128-byte record per node with the boxes of its (up to) four grandchildren,
+  // slot k: (min_k.xyz, reference_k) at +16k, (max_k.xyz, -) at +64 + 16k, node references = byte offsets into this array
+  // (index * 128), SRT_REF_DONE = unused slot; built from nodes2 (srt_lbvh.hip wideNodes).  Null: walk nodes2.
+  const float4* nodes4;
+  int32_t wideStackDepth;  // pending references the wide walk can pile up: 3 per wide level
   // 1 byte per node: the axis its children are split on (left = lower side), 3 = unknown.  Read only by
   // SRT_TRAVERSE_CLOSEST, which visits the nearer child first; FAITHFUL keeps bvh.h's left-then-right.
   const uint8_t* nodeAxis;

@@ -89,16 +89,22 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
   if (!LDSTREE) *stackBase = (StackT)DONE;  // popping the empty stack yields "done"; nothing ever stores to slot 0 again
   // attenuation slots: behind the traversal slots (256-thread kernel), behind the 16 queue words (LDSTREE with room,
   // ATTLDS), or in global memory (LDSTREE with a tree that leaves no room)
-  float* attStack = !LDSTREE ? reinterpret_cast<float*>(lds + stackSlots * BLOCK + threadIdx.x)
-                    : ATTLDS ? reinterpret_cast<float*>(ldsTree + treeBytes + 64) + threadIdx.x
-                             : a.attScratch + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int attStride = LDSTREE && !ATTLDS ? (int)gridDim.x * BLOCK : BLOCK;
+  // (256-thread kernel with RenderArgs::attScratch set: in global memory too -- the closest-hit traversal of a scene far
+  // larger than the caches is bound by requests in flight, and 15 KB less LDS per workgroup is one more workgroup per CU)
+  const bool attGlobal = LDSTREE ? !ATTLDS : a.attScratch != nullptr;
+  float* attStack = attGlobal ? a.attScratch + (size_t)blockIdx.x * BLOCK + threadIdx.x
+                    : !LDSTREE ? reinterpret_cast<float*>(lds + stackSlots * BLOCK + threadIdx.x)
+                               : reinterpret_cast<float*>(ldsTree + treeBytes + 64) + threadIdx.x;
+  const int attStride = attGlobal ? (int)gridDim.x * BLOCK : BLOCK;
+  const int attSlots = attGlobal ? 0 : 3 * a.maxBounce + 3;  // LDS slots per thread behind the traversal stack
   const int lane = threadIdx.x & 63;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
   const DevScene& sc = a.scene;
   const __amdgpu_buffer_rsrc_t rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
   const __amdgpu_buffer_rsrc_t rsNodes2 = makeRsrc(sc.nodes2, CLOSEST ? sc.numNodes * 64 : 0);
+  const bool wide = CLOSEST && sc.nodes4 != nullptr;  // closest-hit traversal over the 128-byte four-box records
+  const __amdgpu_buffer_rsrc_t rsNodes4 = makeRsrc(sc.nodes4, wide ? (int)((unsigned)sc.numNodes * 128u) : 0);
   const __amdgpu_buffer_rsrc_t rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const __amdgpu_buffer_rsrc_t rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
   const __amdgpu_buffer_rsrc_t rsTexels = makeRsrc(sc.texels, sc.texelBytes);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
   // the queues of its own XCD; when none has any left its idle lanes leave.  The wave's current queue
   // lives in one LDS word (-1: everything drained) so that every lane sees it whichever lanes pulled last.
   int32_t* waveQueue = LDSTREE ? reinterpret_cast<int32_t*>(ldsTree + treeBytes) + (threadIdx.x >> 6)
-                               : lds + (stackSlots + 3 * a.maxBounce + 3) * BLOCK + (threadIdx.x >> 6);
+                               : lds + (stackSlots + attSlots) * BLOCK + (threadIdx.x >> 6);
   const int qHome = (int)(blockIdx.x % (unsigned)a.numQueues);
   if (lane == 0) *waveQueue = qHome;
   const int unitItems = a.unitTiles * a.sppChunks * SRT_TILE_PIXELS;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
     }
     if (!SINGLE && !singleRoot && next == DONE && ++w < sc.numWorld) {  // once per ray: next root of the world list
       next = localRef(sc.world[w]);
-      if (CLOSEST && next >= 0) next <<= 1;
+      if (CLOSEST && next >= 0) next <<= (wide ? 2 : 1);
       sptr = stackBase;
       link = DONE_PAIR;
     }
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
     link = DONE_PAIR;
     w = 0;
     cur = localRef(sc.world[0]);
-    if (CLOSEST && cur >= 0) cur <<= 1;  // node references of the closest-hit traversal address the 64-byte records
+    if (CLOSEST && cur >= 0) cur <<= (wide ? 2 : 1);  // node references of the closest-hit traversal address the 64- / 128-byte records
     pend = 1;  // a miss unless a hit-shading step says otherwise
   };
 
@@ -331,6 +337,64 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
           if (COUNT) {
             pSteps[M_NODE]++;
             pLanes[M_NODE] += __popcll(__ballot(atNode()));
+          }
+          if (CLOSEST && wide) {
+            // closest-hit traversal over the 128-byte records (DevScene::nodes4: the boxes of a node's four grandchildren):
+            // one full line per visit, four boxes tested, the nearest entered, the other hits left pending; conservative
+            // one-FMA intervals as below (a box is entered unless it is certainly missed)
+            if (atNode()) {
+              float4 lo[4], hi[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                lo[k] = bufLoad4(rsNodes4, cur + 16 * k);
+                hi[k] = bufLoad4(rsNodes4, cur + 64 + 16 * k);
+              }
+              const int top = *sptr;
+              float t[4];
+              bool h[4];
+              int ref[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                ref[k] = __float_as_int(lo[k].w);
+                h[k] = boxMaybeHit(lo[k], hi[k], rcpD, negOR, slabTol, a.tMin, closest, t[k]);
+              }
+              if (slabTol == SRT_INF) {  // a ray outside the certified operand ranges: the reference's own test (see below)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = boxHit(lo[k], hi[k], ray, a.tMin, closest);
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                h[k] = h[k] && ref[k] != SRT_REF_DONE;
+                t[k] = h[k] ? t[k] : SRT_INF;
+                if (COUNT) {
+                  cNodes += ref[k] != SRT_REF_DONE ? 1 : 0;  // boxes tested, 32 bytes each
+                  cBox += h[k] ? 1 : 0;
+                }
+              }
+              // the nearest hit is entered; the others go on the stack (slot order)
+              const int n01 = t[1] < t[0] ? 1 : 0, n23 = t[3] < t[2] ? 3 : 2;
+              const float t01 = hwMin(t[0], t[1]), t23 = hwMin(t[2], t[3]);
+              const int nearK = t23 < t01 ? n23 : n01;
+              const bool any = h[0] || h[1] || h[2] || h[3];
+              int nearRef = ref[0];
+              nearRef = nearK == 1 ? ref[1] : nearRef;
+              nearRef = nearK == 2 ? ref[2] : nearRef;
+              nearRef = nearK == 3 ? ref[3] : nearRef;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                sptr[BLOCK] = (StackT)ref[k];  // the slot above the top is free; live only if sptr is bumped
+                int move = (h[k] && nearK != k) ? 1 : 0;
+                asm("" : "+v"(move));
+                sptr += move * BLOCK;
+              }
+              if (!any) sptr -= BLOCK;
+              cur = any ? nearRef : top;
+              if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
+                cur = sc.world[w] >= 0 ? sc.world[w] << 2 : sc.world[w];
+                sptr = stackBase;
+              }
+            }
+            return;
           }
           if (CLOSEST) {
             // closest-hit traversal over the 64-byte records (both children's boxes per node, DevScene::nodes2):

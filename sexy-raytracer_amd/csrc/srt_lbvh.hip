@@ -419,6 +419,58 @@ __global__ void pairNodes(DevScene sc, float time0, float time1, float4* out) {
 }
 }  // namespace
 
+// ---- wide records of the closest-hit traversal: FOUR boxes per 128-byte record.
+// nodes4[i] = the grandchildren of binary node i (a child that is a primitive stands for itself): slots k = 0..3 hold
+// (min_k.xyz, reference_k) at +16k and (max_k.xyz, -) at +64 + 16k; node references are byte offsets into this array
+// (index * 128), primitive references as everywhere, SRT_REF_DONE marks an unused slot.  Built from the paired records
+// (pairNodes above) for every node; the traversal only ever reaches the root and the nodes that are somebody's slot.
+// One visit = one full 128-byte line and four box tests; a ray crosses half as many records as with the 64-byte ones.
+namespace {
+__global__ void wideNodes(const float4* nodes2, int numNodes, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes) return;
+  float4 mn[4], mx[4];
+  int n = 0;
+  auto put = [&](float4 lo, float4 hi, int ref) {
+    if (ref == SRT_REF_DONE || ref == 0) return;  // padding
+    for (int k = 0; k < n; ++k)
+      if (__float_as_int(mn[k].w) == ref) return;  // a single-object leaf names its object twice (bvh.h:67-69)
+    mn[n] = make_float4(lo.x, lo.y, lo.z, __int_as_float(ref));
+    mx[n] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+    n++;
+  };
+  auto wideRef = [](int ref) { return ref >= 0 ? (ref >> 6) << 7 : ref; };  // node: byte offset in nodes2 -> in nodes4
+  const float4* me = nodes2 + 4 * (size_t)i;
+  const int childRef[2] = {__float_as_int(me[0].w), __float_as_int(me[1].w)};
+  for (int c = 0; c < 2; ++c) {
+    const int ref = childRef[c];
+    if (ref >= 0 && !(c == 1 && ref == childRef[0])) {  // a node: its two children take slots
+      const float4* ch = nodes2 + 4 * (size_t)(ref >> 6);
+      put(ch[0], ch[1], wideRef(__float_as_int(ch[0].w)));
+      put(ch[2], ch[3], wideRef(__float_as_int(ch[1].w)));
+    } else if (ref < 0) {  // a primitive: its own slot
+      put(me[2 * c], me[2 * c + 1], ref);
+    }
+  }
+  for (int k = n; k < 4; ++k) {
+    mn[k] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(SRT_REF_DONE));
+    mx[k] = make_float4(-1.0f, -1.0f, -1.0f, 0.0f);
+  }
+  for (int k = 0; k < 4; ++k) {
+    out[8 * (size_t)i + k] = mn[k];
+    out[8 * (size_t)i + 4 + k] = mx[k];
+  }
+}
+}  // namespace
+
+extern "C" int srt_wide_nodes(const float4* nodes2, int numNodes, float4* out) {
+  if (numNodes <= 0) return 0;
+  hipLaunchKernelGGL(wideNodes, dim3((numNodes + 255) / 256), dim3(256), 0, nullptr, nodes2, numNodes, out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return (int)e;
+}
+
 extern "C" int srt_pair_nodes(const DevScene* sc, float time0, float time1, float4* out) {
   if (sc->numNodes <= 0) return 0;
   hipLaunchKernelGGL(pairNodes, dim3((sc->numNodes + 255) / 256), dim3(256), 0, nullptr, *sc, time0, time1, out);

@@ -452,6 +452,32 @@ def test_device_builders_on_duplicated_geometry(ctx, oracle, abi, srt, builder):
 
 
 @pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
+def test_closest_hit_record_forms_agree(ctx, abi, srt, camera):
+    """The fast mode's two experimental forms (off by default, profiles/r03/wide_nodes.txt): the closest-hit traversal over
+    128-byte records with four boxes (tunable wide_nodes, read at upload) and with the attenuation stacks in global
+    memory (att_global) must render what the 64-byte two-box records render -- the closest hit does not depend on the
+    records' shape; only exact ties between coincident primitives may fall differently."""
+    saved = {k: ctx.get_tunable(k) for k in ("wide_nodes", "att_global")}
+    try:
+        for make in (lambda: srt.scenes.scene_soup(30000, seed=5, builder=abi.SRT_BUILDER_PLOC), srt.scenes.scene_masterchief,
+                     srt.scenes.scene_sphere_field):
+            images = {}
+            for wide, att in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                ctx.set_tunable("wide_nodes", wide)
+                ctx.set_tunable("att_global", att)  # node-count threshold: 1 = every tree
+                ctx.upload_scene(make())
+                ctx.set_camera(camera)
+                p = abi.default_render_params(160, 90, 4, 8, seed=3, traversal=abi.SRT_TRAVERSE_CLOSEST, spp_chunks=0)
+                images[(wide, att)], _ = ctx.render_image(p)
+            base = images[(0, 0)].view(np.uint32)
+            for key, img in images.items():
+                same = (img.view(np.uint32) == base).all(axis=-1)
+                assert same.mean() > 0.999, (key, same.mean())
+    finally:
+        for k, v in saved.items():
+            ctx.set_tunable(k, v)
+
+
 def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera, builder):
     for count in (1, 2, 3, 37):
         sb = abi.SceneBuilder()

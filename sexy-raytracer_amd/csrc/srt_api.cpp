@@ -739,8 +739,12 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
   auto classOf = [&](float word, bool sphere) -> uint8_t {
     int32_t bits;
     memcpy(&bits, &word, 4);
-    const int type = (bits >> SRT_MAT_TYPE_SHIFT) & 3;
-    return type == SRT_MAT_PBR ? (sphere ? 1 : 0) : 2;
+    const int type = (bits >> SRT_MAT_TYPE_SHIFT) & 3, flags = (bits >> SRT_MAT_FLAGS_SHIFT) & 3;
+    if (type != SRT_MAT_PBR) return 2;
+    if (!sphere) return 0;
+    // a sphere whose pbr material reads uv or a normal map (the textured iron sphere: acosf / atan2f, a tangent frame,
+    // four lookups) would make every hit step of the plain spheres (the ground) run that code too: it goes with "the rest"
+    return flags ? 2 : 1;
   };
   std::vector<uint4> shadeRecs((size_t)8 * d->numMaterials, make_uint4(0, 0, 0, 0));
   for (int i = 0; i < d->numMaterials; ++i) {
@@ -774,6 +778,16 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       } else {
         packed[2 * k] = 3u;  // everything else goes through texValue on the id
         packed[2 * k + 1] = (uint32_t)ids[k];
+      }
+    }
+    // an albedo slot that is checker(solidColor, solidColor): both colours into the record (+80 even, +96 odd)
+    if (m.type == SRT_MAT_PBR && ids[0] >= 0 && texs[ids[0]].kind == SRT_TEX_CHECKER) {
+      const DevTexture& c = texs[ids[0]];
+      if (c.even >= 0 && c.odd >= 0 && c.even < (int)texs.size() && c.odd < (int)texs.size() && texs[c.even].kind == SRT_TEX_SOLID &&
+          texs[c.odd].kind == SRT_TEX_SOLID) {
+        packed[0] = 7u;  // SRT_SLOT_CHECKER2
+        r[5] = make_uint4(f2u(texs[c.even].color[0]), f2u(texs[c.even].color[1]), f2u(texs[c.even].color[2]), 0);
+        r[6] = make_uint4(f2u(texs[c.odd].color[0]), f2u(texs[c.odd].color[1]), f2u(texs[c.odd].color[2]), 0);
       }
     }
     r[3] = make_uint4(packed[0], packed[1], packed[2], packed[3]);

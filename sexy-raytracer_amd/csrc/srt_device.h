@@ -76,8 +76,8 @@ struct DevScene {
   // are two nodes or two primitives, and every reference fits 15 bits (srt_api.cpp threadTree).
   const int32_t* nodeThread;
   // path-pool kernel (srt_wavefront.hip): the material CLASS of every primitive, indexed by ~reference
-  // (index << 1 | sphere): 0 triangle with a pbr material, 1 sphere with a pbr material, 2 anything else.  A hit goes to
-  // its class's ring, so a hit step runs one class's code.
+  // (index << 1 | sphere): 0 triangle with a pbr material, 1 sphere with a pbr material that reads neither uv nor a normal
+  // map, 2 anything else.  A hit goes to its class's ring, so a hit step runs one class's code.
   const uint8_t* primClass;
   int32_t numPrimClass;
   const int32_t* triPrimId;  // device index -> index into the scene's prims[] list

@@ -519,26 +519,25 @@ __device__ __forceinline__ bool piPeriods(float x, int& periods) {
   return r > 1e-6f && r < 1.0f - 1e-6f && fabsf(qh) < 4194304.0f;
 }
 
+// checker::value's choice (texture.h:42-48): is sinf(10x) * sinf(10y) * sinf(10z) negative (the odd texture) at p?
+// Only the sign of the product is used.  sin(a) is negative exactly when floor(a/pi) is odd, and with a/pi at least
+// 1e-6 away from the integers every sine is at least 3e-6 in magnitude: sinf cannot lose its sign and the product
+// cannot underflow, so three range reductions replace three sinf calls.  Arguments that close to a multiple of pi,
+// zero, huge and non-finite ones take the reference's expression.
+__device__ __forceinline__ bool checkerOdd(V3 p) {
+  const float ax = 10.0f * p.x, ay = 10.0f * p.y, az = 10.0f * p.z;
+  int kx, ky, kz;
+  const bool cx = piPeriods(ax, kx), cy = piPeriods(ay, ky), cz = piPeriods(az, kz);
+  if (cx && cy && cz) return ((kx ^ ky ^ kz) & 1) != 0;
+  const float sines = sinf(ax) * sinf(ay) * sinf(az);
+  return sines < 0;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ V3 texValue(const DevScene& sc, Rsrc rsTexels, int id, float u, float v, V3 p, uint32_t& fetches) {
   const DevTexture& t = sc.textures[id];
   if (t.kind == SRT_TEX_CHECKER) {  // texture.h:42-48
-    // Only the sign of sinf(10x)*sinf(10y)*sinf(10z) is used.  sin(a) is negative exactly when
-    // floor(a/pi) is odd, and with a/pi at least 1e-6 away from the integers every sine is at least 3e-6
-    // in magnitude: sinf cannot lose its sign and the product cannot underflow, so three range
-    // reductions replace three sinf calls.  Arguments that close to a multiple of pi, zero, huge and
-    // non-finite ones take the reference's expression.
-    const float ax = 10.0f * p.x, ay = 10.0f * p.y, az = 10.0f * p.z;
-    int kx, ky, kz;
-    const bool cx = piPeriods(ax, kx), cy = piPeriods(ay, ky), cz = piPeriods(az, kz);
-    bool negative;
-    if (cx && cy && cz) {
-      negative = ((kx ^ ky ^ kz) & 1) != 0;
-    } else {
-      float sines = sinf(ax) * sinf(ay) * sinf(az);
-      negative = sines < 0;
-    }
-    int child = negative ? t.odd : t.even;
+    const int child = checkerOdd(p) ? t.odd : t.even;
     return texLeaf<COUNT>(sc, rsTexels, child, u, v, fetches) * 255.0f;
   }
   return texLeaf<COUNT>(sc, rsTexels, id, u, v, fetches);
@@ -566,6 +565,9 @@ __device__ __forceinline__ float schlickGAF(float NdotV, float roughness) {  // 
 //   +32  the emit texture of a light, in full: (mode, width | r, height | g, texel byte offset | b)
 //   +48  pbr: albedo and normal slots, two dwords each: (mode | width << 2 | height << 17, texel byte offset | id)
 //   +64  pbr: metallic and roughness slots, likewise
+//   +80  +96  an albedo slot that is a checker of two solid colours (the ground of every main.cpp scene): the even and
+//        the odd colour, and bit 2 of the slot's first word set -- the hit reads them with the rest of the record instead of
+//        walking texture -> checker -> solidColor descriptors one dependent load after the other
 // Slot modes: 0 no texture, 1 solid colour (also the magenta of a failed load; lights only), 2 image of >= 3 bytes per
 // pixel with both sides below 2^15 (one dword per texel), 3 anything else (checker, solid colour in a pbr slot, 1- and
 // 2-byte images): texValue on the texture id.
@@ -573,6 +575,7 @@ __device__ __forceinline__ float schlickGAF(float NdotV, float roughness) {  // 
 #define SRT_SLOT_SOLID 1u
 #define SRT_SLOT_IMAGE 2u
 #define SRT_SLOT_GENERIC 3u
+#define SRT_SLOT_CHECKER2 7u  // SRT_SLOT_GENERIC | 4: albedo slot only, colours at +80 / +96 of the record
 // byte offset of the texel an image lookup reads (imagePNG::value, texture.h:129-146)
 __device__ __forceinline__ int texelOffset(int width, int height, int base, float u, float v) {
   u = clampf(u, 0.0f, 1.0f);
@@ -678,7 +681,13 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
         auto fetch = [&](uint32_t mw, uint32_t aux, uint32_t early) {
           return WIDE || (mw & 3u) != SRT_SLOT_IMAGE ? early : __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(mw, aux, rec.u, rec.v), 0, 0);
         };
-        if ((tAN.x & 3u) != SRT_SLOT_NONE) a0 = slotValue<COUNT>(sc, rsTexels, tAN.x, tAN.y, fetch(tAN.x, tAN.y, pA), rec.u, rec.v, rec.p, fetches) / 255.0f;
+        if ((tAN.x & 7u) == SRT_SLOT_CHECKER2) {
+          // checker(solidColor, solidColor)::value = the chosen colour times 255 (texture.h:45-47), then material.h:165-166
+          const float4 even = bufLoad4(rsMat, at + 80), odd = bufLoad4(rsMat, at + 96);
+          const float4 c = checkerOdd(rec.p) ? odd : even;
+          a0 = mk(c.x * 255.0f, c.y * 255.0f, c.z * 255.0f) / 255.0f;
+        } else if ((tAN.x & 3u) != SRT_SLOT_NONE)
+          a0 = slotValue<COUNT>(sc, rsTexels, tAN.x, tAN.y, fetch(tAN.x, tAN.y, pA), rec.u, rec.v, rec.p, fetches) / 255.0f;
         if ((tAN.z & 3u) != SRT_SLOT_NONE) {
           V3 nt = slotValue<COUNT>(sc, rsTexels, tAN.z, tAN.w, fetch(tAN.z, tAN.w, pN), rec.u, rec.v, rec.p, fetches);
           nt = mk(nt.x - 128.0f, nt.y - 128.0f, nt.z - 128.0f) / 128.0f;  // vec3.h:103-110

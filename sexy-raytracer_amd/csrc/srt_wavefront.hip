@@ -413,6 +413,11 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           const float4 n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
           bool undecided;
           bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
+          if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
+            const unsigned long long mu = __ballot(undecided);
+            pLanes[8] += __popcll(mu);
+            pLanes[7] += mu != 0 ? 1 : 0;
+          }
           if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
           link = __float_as_int(n1.w);
           cur = hitBox ? __float_as_int(n0.w) : (link >> 16);

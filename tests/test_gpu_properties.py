@@ -451,7 +451,6 @@ def test_device_builders_on_duplicated_geometry(ctx, oracle, abi, srt, builder):
     assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
 
 
-@pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
 def test_closest_hit_record_forms_agree(ctx, abi, srt, camera):
     """The fast mode's two experimental forms (off by default, profiles/r03/wide_nodes.txt): the closest-hit traversal over
     128-byte records with four boxes (tunable wide_nodes, read at upload) and with the attenuation stacks in global
@@ -478,6 +477,7 @@ def test_closest_hit_record_forms_agree(ctx, abi, srt, camera):
             ctx.set_tunable(k, v)
 
 
+@pytest.mark.parametrize("builder", ["LBVH", "PLOC"])
 def test_device_lbvh_small_and_moving(ctx, oracle, abi, camera, builder):
     for count in (1, 2, 3, 37):
         sb = abi.SceneBuilder()

@@ -31,7 +31,7 @@ for l in lines[start:end]:
     if op.endswith("_f64") or "_f64_" in op or op.startswith(("v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64")):
         per[cur]["slow"] += 1
 edges = [int(x) for x in sys.argv[3:]] or None
-src = open(sys.argv[0].replace("tools/isa_profile.py", "sexy-raytracer_amd/csrc/srt_kernels.hip")).read().split("\n") if False else None
+
 tot = collections.Counter()
 for ln in sorted(per):
     tot.update(per[ln])

@@ -31,6 +31,8 @@ for k in ("node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "new_item",
     v = pr[k]
     print("%-10s %5.1f%% of wave time, %11d executions, mean fill %5.1f lanes, %8.1f clocks/execution, %.3f executions/sample" % (
         k, 100.0 * v["clocks"] / tot, v["runs"], v["lanes"] / max(1, v["runs"]), v["clocks"] / max(1, v["runs"]), v["runs"] / samples))
+print("slab certificate: %.4f%% of lane visits undecided, %.2f%% of wave visits ran the IEEE test" % (
+    100.0 * pr["lost_claim"]["lanes"] / max(1, pr["node"]["lanes"]), 100.0 * pr["idle"]["lanes"] / max(1, pr["node"]["runs"])))
 print("%-10s %5.1f%% of wave time, %d decisions (%.2f per sample)" % ("scheduling", 100.0 * pr["sched_clocks"] / tot, pr["decisions"], pr["decisions"] / samples))
 print("a decision saw, on average:", {k: round(v, 1) for k, v in pr["mean_seen"].items() if k in ("at_node", "at_prim", "finished", "idle")})
 sw = max(1, pr["swap"]["runs"])

@@ -668,11 +668,18 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
       V3 a0 = mk(albedo.x, albedo.y, albedo.z), normal = rec.normal;
       float mt = metalness, rg = roughness;
       if (rec.matType & SRT_MAT_TEXTURED) {  // some texture slot is in use: skipped by waves whose hits have none
+        // WIDE: the whole record in one round trip (slots, and the two colours of a checker-of-solids albedo), then the
+        // four texel loads together when any slot is an image (an absent or non-image slot reads texel 0 of the buffer and
+        // ignores it); otherwise each load is made where its value is used
         const u32x4 tAN = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at + 48, 0, 0), tMR = __builtin_amdgcn_raw_buffer_load_b128(rsMat, at + 64, 0, 0);
-        // WIDE: the four texel loads go out together (an absent or non-image slot reads texel 0 of the buffer and
-        // ignores it); otherwise each is made where its value is used
-        uint32_t pA = 0, pN = 0, pM = 0, pR = 0;
+        float4 even = make_float4(0.0f, 0.0f, 0.0f, 0.0f), odd = even;
         if (WIDE) {
+          even = bufLoad4(rsMat, at + 80);
+          odd = bufLoad4(rsMat, at + 96);
+        }
+        uint32_t pA = 0, pN = 0, pM = 0, pR = 0;
+        const bool anyImage = (tAN.x & 3u) == SRT_SLOT_IMAGE || (tAN.z & 3u) == SRT_SLOT_IMAGE || (tMR.x & 3u) == SRT_SLOT_IMAGE || (tMR.z & 3u) == SRT_SLOT_IMAGE;
+        if (WIDE && anyImage) {
           pA = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tAN.x, tAN.y, rec.u, rec.v), 0, 0);
           pN = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tAN.z, tAN.w, rec.u, rec.v), 0, 0);
           pM = __builtin_amdgcn_raw_buffer_load_b32(rsTexels, slotTexelOffset(tMR.x, tMR.y, rec.u, rec.v), 0, 0);
@@ -683,7 +690,10 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
         };
         if ((tAN.x & 7u) == SRT_SLOT_CHECKER2) {
           // checker(solidColor, solidColor)::value = the chosen colour times 255 (texture.h:45-47), then material.h:165-166
-          const float4 even = bufLoad4(rsMat, at + 80), odd = bufLoad4(rsMat, at + 96);
+          if (!WIDE) {
+            even = bufLoad4(rsMat, at + 80);
+            odd = bufLoad4(rsMat, at + 96);
+          }
           const float4 c = checkerOdd(rec.p) ? odd : even;
           a0 = mk(c.x * 255.0f, c.y * 255.0f, c.z * 255.0f) / 255.0f;
         } else if ((tAN.x & 3u) != SRT_SLOT_NONE)

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       }
       idleTrips = 0;
       if (PROFILE) {
-        pSaw[0]++; pSaw[1] += nN; pSaw[2] += nP; pSaw[3] += nF; pSaw[4] += nI;
+        pSaw[0]++;
         (void)readyAvail;
       }
     } else {
@@ -485,6 +485,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     } else if (pick == W_SERVE) {
       // ------------------------------------------------ serve a ring: 64 contexts in the same state
       int id;
+      const unsigned long long h0 = PROFILE ? clock64() : 0;
       const int k = claim(bestRing, ~0ull, 64, serveAtLeast, id);
       if (k == 0) {  // another wave took them
         prof(8, 0);
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           rng.state = (uint64_t)C.x | ((uint64_t)C.y << 32);
           int depth = (int)(C.w & 0xffu);
           Record rec;
+          const unsigned long long h1 = PROFILE ? clock64() : 0;
           if (pr & 1)
             sphereRecord(sc, pr >> 1, rIn, tHit, rec, false);
           else
@@ -514,7 +516,15 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           V3 att, emitted;
           Ray next;
           uint32_t fetches = 0;
+          const unsigned long long h2 = PROFILE ? clock64() : 0;
           const bool scattered = shade<false, true>(sc, rsTexels, rIn, rec, rng, att, next, emitted, fetches, nullptr);
+          if (PROFILE && bestRing == WF_RING_HIT + 1) {  // the ground's class: claim + context / record / shade (lane 0's clocks)
+            const unsigned long long h3 = clock64();
+            pSaw[1] += h1 - h0;
+            pSaw[2] += h2 - h1;
+            pSaw[3] += h3 - h2;
+            pSaw[4] += 1;
+          }
           V3 terminal = emitted;  // main.cpp:46-47
           bool done = true;
           if (scattered) {

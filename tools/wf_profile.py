@@ -34,8 +34,10 @@ for k in ("node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "new_item",
 print("slab certificate: %.4f%% of lane visits undecided, %.2f%% of wave visits ran the IEEE test" % (
     100.0 * pr["lost_claim"]["lanes"] / max(1, pr["node"]["lanes"]), 100.0 * pr["idle"]["lanes"] / max(1, pr["node"]["runs"])))
 print("%-10s %5.1f%% of wave time, %d decisions (%.2f per sample)" % ("scheduling", 100.0 * pr["sched_clocks"] / tot, pr["decisions"], pr["decisions"] / samples))
-print("a decision saw, on average:", {k: round(v, 1) for k, v in pr["mean_seen"].items() if k in ("at_node", "at_prim", "finished", "idle")})
 sw = max(1, pr["swap"]["runs"])
 ms_ = pr["mean_seen"]
+h1n = max(1.0, ms_["idle"] * pr["decisions"])
+print("hit step of class 1 (%d timed): claim + context %.0f clocks, hit record %.0f, shade %.0f (the rest: stores, fence, hand-over)" % (
+    h1n, ms_["at_node"] * pr["decisions"] / h1n, ms_["at_prim"] * pr["decisions"] / h1n, ms_["finished"] * pr["decisions"] / h1n))
 print("swap step: claim %.0f clocks, hand-over %.0f, arrival + set-up %.0f" % tuple(ms_[k] * pr["decisions"] / sw for k in ("ready_fill", "fullest_ring", "restart_fill")))
 ctx.close()

@@ -287,16 +287,113 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       pT = now;
     }
   };
+  // ---- the two traversal steps (as srt_render_kernel's, over the threaded tree in LDS)
+  auto primStep = [&]() -> int {  // returns the lanes at nodes afterwards
+    int nNodes;
+      // ------------------------------------------------ sphere::hit / triangle::hit (as srt_render_kernel)
+      for (int round = 0; round < SRT_PRIM_ROUNDS; ++round) {
+        if (round > 0 && __popcll(__ballot(atPrim())) < a.primAgainMin) break;
+        if (PROFILE) {
+          pRuns[1]++;
+          pLanes[1] += __popcll(__ballot(atPrim()));
+        }
+        if (atPrim()) {
+          const int pr = ~cur;
+          float t;
+          bool ok;
+          if (pr & 1) {
+            const int off = (pr >> 1) * 48;
+            const float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
+            V3 center = mk(s0.x, s0.y, s0.z);
+            if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
+              const float4 s2 = bufLoad4(rsSpheres, off + 32);
+              center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
+            }
+            ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
+          } else {
+            const int off = (pr >> 1) * 48;
+            ok = triHitV<false>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray, a.tMin, closest, t);
+          }
+          if (ok) {
+            closest = t;
+            hitRef = cur;
+          }
+          popNext();
+        }
+      }
+      nNodes = __popcll(__ballot(atNode()));
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pCyc[1] += now - pT;
+        pT = now;
+      }
+      return nNodes;
+  };
+  auto nodeBurst = [&](int nNodes) {
+      // ------------------------------------------------ bvhNode::hit, bvh.h:97-105, over the threaded tree in LDS
+      const int keep = (nNodes * a.keepEighths) >> 3;
+      int budget = a.nodeBurst;
+      auto nodeVisit = [&]() {
+        if (PROFILE) {
+          pRuns[0]++;
+          pLanes[0] += __popcll(__ballot(atNode()));
+        }
+        if (atNode()) {
+          const float4 n0 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5));
+          const float4 n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
+          bool undecided;
+          bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
+          if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
+            const unsigned long long mu = __ballot(undecided);
+            pLanes[8] += __popcll(mu);
+            pLanes[7] += mu != 0 ? 1 : 0;
+          }
+          if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+          link = __float_as_int(n1.w);
+          cur = hitBox ? __float_as_int(n0.w) : (link >> 16);
+          if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
+            cur = localRef(sc.world[w]);
+            link = DONE_PAIR;
+          }
+        }
+      };
+      do {
+#pragma unroll
+        for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
+        budget -= SRT_NODE_UNROLL;
+      } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pCyc[0] += now - pT;
+        pT = now;
+      }
+  };
   for (;;) {
-    // ---- scheduling decision
-    const unsigned long long mN = __ballot(atNode()), mP = __ballot(atPrim()), mF = __ballot(cur == DONE && path >= 0),
-                             mI = __ballot(path < 0);
-    const int nN = __popcll(mN), nP = __popcll(mP), nF = __popcll(mF), nI = __popcll(mI);
-    const int free = nF + nI;
+    // ---- traverse for as long as the rings need no look: a tight loop of node bursts and primitive steps.  The rings are
+    // looked at (below) when this wave has lanes to refill, nothing to traverse, or every fourth pass: with sixteen waves
+    // deciding, a full batch is still seen within a fraction of the time it took to fill.
+    int nN, nP, free;
+    for (;;) {
+      nN = __popcll(__ballot(atNode()));
+      nP = __popcll(__ballot(atPrim()));
+      free = 64 - nN - nP;  // lanes whose walk is over or that hold no context (cur == DONE either way)
+      if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) break;
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pSched += now - pT;
+        pT = now;
+      }
+      if (nP >= a.primMin || nN == 0) {
+        const int nNodes = primStep();
+        if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+      } else {
+        nodeBurst(nN);
+      }
+    }
+    // ---- scheduling decision with the rings in view
+    const int nF = __popcll(__ballot(cur == DONE && path >= 0));
     int pick, serveAtLeast = 64, bestRing = WF_RING_RESTART;
-    // The rings are looked at when this wave has lanes to refill, nothing to traverse, or every fourth decision: with
-    // sixteen waves deciding, a full batch is still seen within a fraction of the time it took to fill.
-    if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) {
+    {
       unsigned long long* cw = reinterpret_cast<unsigned long long*>(ctl + 16);
       // relaxed 64-bit atomic loads: fresh values every time, two words per LDS read, broadcast to the wave
       const unsigned long long w0 = __hip_atomic_load(cw + 0, __ATOMIC_RELAXED, WF_WG), w1 = __hip_atomic_load(cw + 1, __ATOMIC_RELAXED, WF_WG),
@@ -347,9 +444,6 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         pSaw[0]++;
         (void)readyAvail;
       }
-    } else {
-      pick = nP >= a.primMin ? W_PRIM : W_NODE;  // nN + nP > 0 here; a wave with only a few lanes at primitives and none at nodes:
-      if (nN == 0) pick = W_PRIM;
     }
     if (PROFILE) {
       const unsigned long long now = clock64();
@@ -357,86 +451,11 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       pT = now;
     }
 
-    int nNodes = nN;
     if (pick == W_PRIM) {
-      // ------------------------------------------------ sphere::hit / triangle::hit (as srt_render_kernel)
-      for (int round = 0; round < SRT_PRIM_ROUNDS; ++round) {
-        if (round > 0 && __popcll(__ballot(atPrim())) < a.primAgainMin) break;
-        if (PROFILE) {
-          pRuns[1]++;
-          pLanes[1] += __popcll(__ballot(atPrim()));
-        }
-        if (atPrim()) {
-          const int pr = ~cur;
-          float t;
-          bool ok;
-          if (pr & 1) {
-            const int off = (pr >> 1) * 48;
-            const float4 s0 = bufLoad4(rsSpheres, off), s1 = bufLoad4(rsSpheres, off + 16);
-            V3 center = mk(s0.x, s0.y, s0.z);
-            if (__float_as_int(s1.w) & (1 << 30)) {  // sphere.h:47-52
-              const float4 s2 = bufLoad4(rsSpheres, off + 32);
-              center = center + ((ray.time - s2.x) / (s2.y - s2.x)) * (mk(s1.x, s1.y, s1.z) - center);
-            }
-            ok = sphereHitV(center, s0.w, ray, rayA, a.tMin, closest, t);
-          } else {
-            const int off = (pr >> 1) * 48;
-            ok = triHitV<false>(bufLoad4(rsTris, off), bufLoad4(rsTris, off + 16), bufLoad4(rsTris, off + 32), ray, a.tMin, closest, t);
-          }
-          if (ok) {
-            closest = t;
-            hitRef = cur;
-          }
-          popNext();
-        }
-      }
-      nNodes = __popcll(__ballot(atNode()));
-      if (PROFILE) {
-        const unsigned long long now = clock64();
-        pCyc[1] += now - pT;
-        pT = now;
-      }
-      if (nNodes >= a.fuseMin) pick = W_NODE;
-    }
-
-    if (pick == W_NODE) {
-      // ------------------------------------------------ bvhNode::hit, bvh.h:97-105, over the threaded tree in LDS
-      const int keep = (nNodes * a.keepEighths) >> 3;
-      int budget = a.nodeBurst;
-      auto nodeVisit = [&]() {
-        if (PROFILE) {
-          pRuns[0]++;
-          pLanes[0] += __popcll(__ballot(atNode()));
-        }
-        if (atNode()) {
-          const float4 n0 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5));
-          const float4 n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
-          bool undecided;
-          bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
-          if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
-            const unsigned long long mu = __ballot(undecided);
-            pLanes[8] += __popcll(mu);
-            pLanes[7] += mu != 0 ? 1 : 0;
-          }
-          if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
-          link = __float_as_int(n1.w);
-          cur = hitBox ? __float_as_int(n0.w) : (link >> 16);
-          if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
-            cur = localRef(sc.world[w]);
-            link = DONE_PAIR;
-          }
-        }
-      };
-      do {
-#pragma unroll
-        for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
-        budget -= SRT_NODE_UNROLL;
-      } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
-      if (PROFILE) {
-        const unsigned long long now = clock64();
-        pCyc[0] += now - pT;
-        pT = now;
-      }
+      const int nNodes = primStep();
+      if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+    } else if (pick == W_NODE) {
+      nodeBurst(nN);
     } else if (pick == W_SWAP) {
       // ------------------------------------------------ finished walks out, READY contexts in.  The new rays' lines are
       // asked for first and arrive while the finished walks are handed over (LDS traffic only).

@@ -347,7 +347,7 @@ const TunableName kTunables[] = {
     {"lds_tree", "SRT_LDS_TREE", &Tunables::ldsTree, 1},  // FAITHFUL: node records in LDS when the whole array fits and has this many nodes; 0 = never
     // the path-pool kernel (srt_wavefront.hip) for the launches the LDS-resident tree serves whose tree has at least this
     // many nodes (traversal-heavy frames gain, shading-heavy ones with tiny trees lose: profiles/r03/wavefront.txt); 0 = never
-    {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 512},
+    {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 256},
     {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 2048},       // path contexts per workgroup (1024 lanes traverse)
     {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 32},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},

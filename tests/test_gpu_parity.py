@@ -273,7 +273,7 @@ def test_full_sample_count_rows_vs_oracle(ctx, dev, oracle, abi, scenes, camera,
     p = abi.default_render_params(W, H, spp, mb, seed=11, spp_chunks=0)
     acc, rgba = ctx.render_image(p)
     info = ctx.launch_info()
-    assert info["lds_tree"] and info["wavefront"] == (name == "masterchief"), info  # the default kernels for these scenes (trees of >= 512 nodes: path pool)
+    assert info["lds_tree"] and info["wavefront"] == (name == "masterchief"), info  # the default kernels for these scenes (trees of >= 256 nodes: path pool)
     chunks = dev.plan_spp_chunks(W, H, spp, 0)
     assert chunks == dev.default_spp_chunks(spp)
     osc = oracle.OracleScene(sb)

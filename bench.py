@@ -68,6 +68,9 @@ WORKLOADS = {
     "spheres_240p_64spp": ("spheres", 426, 240, 64, 8, "reference", "faithful", "valu-issue"),                # configs[0]
     "masterchief_1080p_8192spp": ("masterchief", 1920, 1080, 8192, 4, "reference", "faithful", "valu-issue"), # configs[4]
     "sphere_field_720p_1024spp": ("sphere_field", 1280, 720, 1024, 8, "reference", "faithful", "valu-issue"),  # main.cpp:92-122
+    # a tree that is cache-resident but does not fit a CU's LDS (66 k nodes, 2 MB): the 256-thread kernel's regime, bound by
+    # the vector-memory address unit (what treelets are for)
+    "soup_50k_720p_64spp": ("soup:50000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),
     # HBM-bound points (SURVEY 8d "Synthetic"): the parity path (reference tree, bvh.h order) and the
     # fast mode (device-built PLOC tree, closest-hit traversal)
     "soup_1m_720p_16spp": ("soup:1000000", 1280, 720, 16, 4, "reference", "faithful", "hbm"),

@@ -67,15 +67,23 @@ __device__ __forceinline__ uint32_t bufLoad1(Rsrc r, int off) { return __builtin
 // SINGLE: the world list is one tree (as in srt_render_kernel).  PROFILE (tunable wf_profile, tools/wf_profile.py): per
 // step kind, the clocks the waves spent in it, its executions and the lanes they served -> RenderArgs::stats[32 + ...]
 // (kinds: 0 node visit, 1 primitive test, 2 swap, 3-5 hit step per class, 6 restart, 7 idle, 8 lost claim, 9 item pull).
+// SWEEP: the tree does NOT fit a CU's LDS (up to 32 766 nodes: what the 16-bit thread links address).  In the threaded
+// pre-order tree a walk's node index only ever grows -- a hit goes to the next record, a miss to a later one -- so a ray
+// sweeps through the node array once, left to right, and the workgroup can stream the array through LDS in blocks of
+// RenderArgs::wfBlockNodes records: barrier, copy block b in, barrier, every lane whose walk stands inside the block
+// advances until it leaves it (lanes further on wait, nobody is ever behind), next block.  Between sweeps the workgroup
+// hands the finished walks to the rings, serves the rings empty in barrier-separated rounds (full waves, one class per
+// hit step, as above) and takes READY contexts for the next sweep.  Same records, same arithmetic, same bits.
 #define WF_PROF_KINDS 10
-template <bool SINGLE, bool PROFILE>
+template <bool SINGLE, bool PROFILE, bool SWEEP>
 __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const RenderArgs a) {
+
   constexpr int32_t DONE = (int32_t)0xFFFF8000;       // the 16-bit "no reference", sign-extended
   constexpr int32_t DONE_PAIR = (int32_t)0x80008000;  // both halves of a thread link
   extern __shared__ int32_t lds[];
   const DevScene& sc = a.scene;
   char* const ldsTree = reinterpret_cast<char*>(lds);
-  const int treeBytes = sc.numNodes * 32;
+  const int treeBytes = (SWEEP ? a.wfBlockNodes : sc.numNodes) * 32;
   int32_t* const ctl = reinterpret_cast<int32_t*>(ldsTree + treeBytes);
   const int RCAP = a.wfRingCap, POOL = a.wfPoolSize;
   uint16_t* const ringSlots = reinterpret_cast<uint16_t*>(ctl + WF_CTL_WORDS);
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   // ---- set-up: the threaded tree into LDS (as srt_render_kernel LDSTREE), empty rings, every context waits for an item
   {
     float4* dst = reinterpret_cast<float4*>(ldsTree);
-    for (int i = threadIdx.x; i < sc.numNodes * 2; i += WF_BLOCK) {
+    for (int i = threadIdx.x; i < (SWEEP ? 0 : sc.numNodes * 2); i += WF_BLOCK) {
       float4 v = bufLoad4(rsNodes, 16 * i);
       const int r = __float_as_int(v.w);
       if (i & 1)
@@ -227,7 +235,9 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   ray.time = 0.0f;
   float closest = SRT_INF, rayA = 0.0f, slabTol = SRT_INF;
   V3 rcpD = mk(0.0f, 0.0f, 0.0f), negOR = mk(0.0f, 0.0f, 0.0f);
-  auto atNode = [&]() { return cur >= 0; };
+  // SWEEP: the block of the node array that is in LDS: records [blkLo, blkHi).  A walk never stands before it.
+  int blkLo = 0, blkHi = SWEEP ? 0 : 0x7fffffff;
+  auto atNode = [&]() { return SWEEP ? (uint32_t)cur < (uint32_t)blkHi : cur >= 0; };  // at a node whose record is in LDS
   auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)DONE; };
   auto popNext = [&]() {
     int next = (int32_t)(int16_t)link;
@@ -339,8 +349,9 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           pLanes[0] += __popcll(__ballot(atNode()));
         }
         if (atNode()) {
-          const float4 n0 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5));
-          const float4 n1 = *reinterpret_cast<const float4*>(ldsTree + (cur << 5) + 16);
+          const char* rec = ldsTree + ((cur - (SWEEP ? blkLo : 0)) << 5);
+          const float4 n0 = *reinterpret_cast<const float4*>(rec);
+          const float4 n1 = *reinterpret_cast<const float4*>(rec + 16);
           bool undecided;
           bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
           if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
@@ -368,95 +379,8 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         pT = now;
       }
   };
-  for (;;) {
-    // ---- traverse for as long as the rings need no look: a tight loop of node bursts and primitive steps.  The rings are
-    // looked at (below) when this wave has lanes to refill, nothing to traverse, or every fourth pass: with sixteen waves
-    // deciding, a full batch is still seen within a fraction of the time it took to fill.
-    int nN, nP, free;
-    for (;;) {
-      nN = __popcll(__ballot(atNode()));
-      nP = __popcll(__ballot(atPrim()));
-      free = 64 - nN - nP;  // lanes whose walk is over or that hold no context (cur == DONE either way)
-      if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) break;
-      if (PROFILE) {
-        const unsigned long long now = clock64();
-        pSched += now - pT;
-        pT = now;
-      }
-      if (nP >= a.primMin || nN == 0) {
-        const int nNodes = primStep();
-        if (nNodes >= a.fuseMin) nodeBurst(nNodes);
-      } else {
-        nodeBurst(nN);
-      }
-    }
-    // ---- scheduling decision with the rings in view
-    const int nF = __popcll(__ballot(cur == DONE && path >= 0));
-    int pick, serveAtLeast = 64, bestRing = WF_RING_RESTART;
-    {
-      unsigned long long* cw = reinterpret_cast<unsigned long long*>(ctl + 16);
-      // relaxed 64-bit atomic loads: fresh values every time, two words per LDS read, broadcast to the wave
-      const unsigned long long w0 = __hip_atomic_load(cw + 0, __ATOMIC_RELAXED, WF_WG), w1 = __hip_atomic_load(cw + 1, __ATOMIC_RELAXED, WF_WG),
-                               w2 = __hip_atomic_load(cw + 2, __ATOMIC_RELAXED, WF_WG), w3 = __hip_atomic_load(cw + 3, __ATOMIC_RELAXED, WF_WG),
-                               w4 = __hip_atomic_load(cw + 4, __ATOMIC_RELAXED, WF_WG), w5 = __hip_atomic_load(cw + 5, __ATOMIC_RELAXED, WF_WG),
-                               w6 = __hip_atomic_load(cw + 6, __ATOMIC_RELAXED, WF_WG);
-      // words 16 + 2r / 17 + 2r tail / head of ring r, 28 live, 29 abort
-      if ((int)(w6 >> 32) != 0) break;  // abort
-      auto fill = [](unsigned long long th) { return (int)((uint32_t)th - (uint32_t)(th >> 32)); };
-      const int readyAvail = __builtin_amdgcn_readfirstlane(fill(w0));
-      const int av[5] = {fill(w1), fill(w2), fill(w3), fill(w4), fill(w5)};  // RESTART, HIT 0..2, NEWITEM
-      int bestAvail = av[0];
-#pragma unroll
-      for (int r = 1; r < 5; ++r)
-        if (av[r] > bestAvail) {
-          bestAvail = av[r];
-          bestRing = WF_RING_RESTART + r;
-        }
-      bestRing = __builtin_amdgcn_readfirstlane(bestRing);
-      bestAvail = __builtin_amdgcn_readfirstlane(bestAvail);
-      // what a swap would move: finished walks out, READY contexts into the lanes without one
-      const int swapGain = nF + (readyAvail < free ? readyAvail : free);
-      if (bestAvail >= 64)
-        pick = W_SERVE;  // a full batch is always worth a step (and feeds READY)
-      else if (swapGain >= a.wfSwapMin)
-        pick = W_SWAP;
-      else if (nP >= a.primMin || (nN == 0 && nP > 0))
-        pick = W_PRIM;
-      else if (nN > 0)
-        pick = W_NODE;
-      else if (swapGain > 0)
-        pick = W_SWAP;
-      else if (bestAvail > 0) {
-        pick = W_SERVE;  // nothing to traverse here and nothing READY: serve what there is
-        serveAtLeast = 1;
-      } else {
-        if (__builtin_amdgcn_readfirstlane((int)w6) <= 0) break;  // every context has retired
-        if (++idleTrips > WF_SPIN_LIMIT) {
-          raiseAbort();
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        prof(7, 0);
-        continue;
-      }
-      idleTrips = 0;
-      if (PROFILE) {
-        pSaw[0]++;
-        (void)readyAvail;
-      }
-    }
-    if (PROFILE) {
-      const unsigned long long now = clock64();
-      pSched += now - pT;
-      pT = now;
-    }
-
-    if (pick == W_PRIM) {
-      const int nNodes = primStep();
-      if (nNodes >= a.fuseMin) nodeBurst(nNodes);
-    } else if (pick == W_NODE) {
-      nodeBurst(nN);
-    } else if (pick == W_SWAP) {
+  // ---- swap step: finished walks out, READY contexts in
+  auto swapStep = [&]() {
       // ------------------------------------------------ finished walks out, READY contexts in.  The new rays' lines are
       // asked for first and arrive while the finished walks are handed over (LDS traffic only).
       const bool fin = cur == DONE && path >= 0;
@@ -501,14 +425,16 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         pSaw[7] += q3 - q2;  // swap: new rays arrive, set-up
       }
       prof(2, __popcll(__ballot(fin)) + __popcll(__ballot(id >= 0)));
-    } else if (pick == W_SERVE) {
+  };
+  // ---- serve step: up to 64 contexts of ring `bestRing` (none unless `serveAtLeast` are there); returns how many
+  auto serveStep = [&](int bestRing, int serveAtLeast) -> int {
       // ------------------------------------------------ serve a ring: 64 contexts in the same state
       int id;
       const unsigned long long h0 = PROFILE ? clock64() : 0;
       const int k = claim(bestRing, ~0ull, 64, serveAtLeast, id);
       if (k == 0) {  // another wave took them
         prof(8, 0);
-        continue;
+        return 0;
       }
       const int at = id << 7;
       if (bestRing >= WF_RING_HIT && bestRing < WF_RING_HIT + WF_CLASSES) {
@@ -732,25 +658,259 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         if (mR != 0 && lane == __ffsll((long long)mR) - 1) __hip_atomic_fetch_sub(&ctl[WF_CTL_LIVE], __popcll(mR), __ATOMIC_RELAXED, WF_WG);
         prof(9, k);
       }
-    }
-  }
+      return k;
+  };
+  auto flushProfile = [&]() {
   if (PROFILE && a.stats && lane == 0) {
-    for (int k = 0; k < WF_PROF_KINDS; ++k) {
-      atomicAdd(&a.stats[32 + k], pCyc[k]);
-      atomicAdd(&a.stats[32 + WF_PROF_KINDS + k], pRuns[k]);
-      atomicAdd(&a.stats[32 + 2 * WF_PROF_KINDS + k], pLanes[k]);
+      for (int k = 0; k < WF_PROF_KINDS; ++k) {
+        atomicAdd(&a.stats[32 + k], pCyc[k]);
+        atomicAdd(&a.stats[32 + WF_PROF_KINDS + k], pRuns[k]);
+        atomicAdd(&a.stats[32 + 2 * WF_PROF_KINDS + k], pLanes[k]);
+      }
+      atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS], pSched);
+      atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 1], (unsigned long long)(clock64() - pStart));
+      for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 2 + k], pSaw[k]);
     }
-    atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS], pSched);
-    atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 1], (unsigned long long)(clock64() - pStart));
-    for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 2 + k], pSaw[k]);
+  };
+  if (SWEEP) {
+    // ================================================= the tree streamed through LDS, block by block
+    // Two roles, fixed per wave for the launch.  TRAVERSAL waves (the first a.wfSweepWaves of the sixteen) move in step
+    // through the blocks: a barrier of their own (an LDS counter: the servers never take part), copy block b in, barrier,
+    // advance their lanes inside it; at the end of a sweep they hand the finished walks to the rings and take READY
+    // contexts.  SERVER waves serve the rings all the time (full batches; partial ones when READY runs low), so that
+    // shading overlaps with the sweeps instead of stretching every block step.
+    const int BN = a.wfBlockNodes, NB = (sc.numNodes + BN - 1) / BN;
+    const int wavesT = a.wfSweepWaves, waveId = threadIdx.x >> 6;
+    int32_t* const bar = &ctl[30];  // arrivals of the traversal waves' barrier (monotone); ctl[31]: 1 = the traversal waves have left
+    auto ringFill = [&](int r) -> int {
+      const unsigned long long th = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&ctl[WF_CTL_TAIL(r)]), __ATOMIC_RELAXED, WF_WG);
+      return __builtin_amdgcn_readfirstlane((int)((uint32_t)th - (uint32_t)(th >> 32)));
+    };
+    auto word = [&](int i) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[i], __ATOMIC_RELAXED, WF_WG)); };
+    if (waveId >= wavesT) {
+      // ---------------------------------------------- a server wave
+      for (int idle = 0;;) {
+        if (word(WF_CTL_ABORT) != 0) break;
+        const bool hungry = ringFill(WF_RING_READY) < 64 * wavesT;  // the traversal waves will run short: partial batches too
+        bool did = false;
+        for (int r = WF_RING_RESTART; r < WF_RINGS && !did; ++r) {
+          const int n = ringFill(r);
+          if (n >= 64 || (hungry && n > 0)) did = serveStep(r, n >= 64 ? 64 : 1) > 0;
+        }
+        if (did) {
+          idle = 0;
+          continue;
+        }
+        if (word(WF_CTL_LIVE) <= 0 || word(31) != 0) break;  // every context has retired / the traversal waves are gone
+        if (++idle > WF_SPIN_LIMIT) {
+          raiseAbort();
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+        prof(7, 0);
+      }
+      flushProfile();
+      return;
+    }
+    // ---------------------------------------------- a traversal wave
+    int epoch = 0;
+    bool gaveUp = false;
+    auto travBarrier = [&]() {  // all traversal waves; what they wrote to LDS before is visible after
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, WF_WG);
+      epoch++;
+      for (int spins = 0; word(30) - epoch * wavesT < 0;) {
+        if (++spins > WF_SPIN_LIMIT || word(WF_CTL_ABORT) != 0) {
+          raiseAbort();
+          gaveUp = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto retireStep = [&]() {  // finished walks -> rings (a swap without the taking)
+      const bool fin = cur == DONE && path >= 0;
+      const bool hit = fin && hitRef != DONE;
+      int cls = 0;
+      if (hit) {
+        cls = (int)__builtin_amdgcn_raw_buffer_load_b8(rsClass, ~hitRef, 0, 0);
+        __hip_atomic_store(&hitT[path], closest, __ATOMIC_RELAXED, WF_WG);
+        __hip_atomic_store(&hitPrim[path], (uint16_t)hitRef, __ATOMIC_RELAXED, WF_WG);
+      }
+      asm volatile("" ::: "memory");
+      enqueue(!fin ? -1 : (hit ? WF_RING_HIT + cls : WF_RING_RESTART), path);
+      if (fin) {
+        path = -1;
+        hitRef = DONE;
+      }
+    };
+    for (;;) {
+      // ---- every walk of the last sweep is over: contexts out, READY contexts in
+      retireStep();
+      {
+        int id = -1;
+        claim(WF_RING_READY, ~0ull, 64, 1, id);
+        if (PROFILE) {
+          pSaw[0]++;                                   // sweeps
+          pSaw[1] += __popcll(__ballot(id >= 0));      // rays taken
+        }
+        if (id >= 0) {
+          const float4 A = bufLoad4(rsPool, id << 7), B = bufLoad4(rsPool, (id << 7) + 16);
+          ray.o = mk(A.x, A.y, A.z);
+          ray.d = mk(B.x, B.y, B.z);
+          ray.time = A.w;
+          path = id;
+          startTraversal();
+        }
+      }
+      // ---- do the traversal waves go on?  Wave 0 decides between two barriers, so that all of them read the same word:
+      // on while a context is alive (a wave without rays sweeps along, which costs a few microseconds, and asks again)
+      prof(2, 0);  // hand-over + taking
+      travBarrier();
+      if (waveId == 0 && lane == 0)
+        __hip_atomic_store(&ctl[31], (word(WF_CTL_LIVE) <= 0 || word(WF_CTL_ABORT) != 0) ? 1 : 0, __ATOMIC_RELAXED, WF_WG);
+      travBarrier();
+      prof(8, 0);  // the two barriers of the go / stop decision
+      if (word(31) != 0 || gaveUp) break;
+      // ---- the sweep
+      for (int blk = 0; blk < NB && !gaveUp; ++blk) {
+        travBarrier();  // everybody is done with the block that is in LDS
+        prof(7, 0);     // waiting for the slowest traversal wave
+        blkLo = blk * BN;
+        blkHi = min(sc.numNodes, blkLo + BN);
+        float4* dst = reinterpret_cast<float4*>(ldsTree);
+        for (int i = threadIdx.x; i < (blkHi - blkLo) * 2; i += wavesT * 64) {
+          const int g = 2 * blkLo + i;
+          float4 v = bufLoad4(rsNodes, 16 * g);
+          const int r = __float_as_int(v.w);
+          if (g & 1)
+            v.w = __int_as_float(sc.nodeThread[g >> 1]);
+          else if (r >= 0)
+            v.w = __int_as_float(r >> 5);
+          dst[i] = v;
+        }
+        travBarrier();
+        prof(9, 0);  // block copy (+ its barrier)
+        for (;;) {  // this wave's lanes inside the block, and those at primitives, until none is left
+          const int nN = __popcll(__ballot(atNode())), nP = __popcll(__ballot(atPrim()));
+          if (nN + nP == 0) break;
+          if (nP >= a.primMin || nN == 0) {
+            const int nNodes = primStep();
+            if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+          } else {
+            nodeBurst(nN);
+          }
+        }
+      }
+      blkHi = 0;  // nothing is at a node now: every walk is over
+    }
+    flushProfile();
+    return;
   }
+  for (;;) {
+    // ---- traverse for as long as the rings need no look: a tight loop of node bursts and primitive steps.  The rings are
+    // looked at (below) when this wave has lanes to refill, nothing to traverse, or every fourth pass: with sixteen waves
+    // deciding, a full batch is still seen within a fraction of the time it took to fill.
+    int nN, nP, free;
+    for (;;) {
+      nN = __popcll(__ballot(atNode()));
+      nP = __popcll(__ballot(atPrim()));
+      free = 64 - nN - nP;  // lanes whose walk is over or that hold no context (cur == DONE either way)
+      if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) break;
+      if (PROFILE) {
+        const unsigned long long now = clock64();
+        pSched += now - pT;
+        pT = now;
+      }
+      if (nP >= a.primMin || nN == 0) {
+        const int nNodes = primStep();
+        if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+      } else {
+        nodeBurst(nN);
+      }
+    }
+    // ---- scheduling decision with the rings in view
+    const int nF = __popcll(__ballot(cur == DONE && path >= 0));
+    int pick, serveAtLeast = 64, bestRing = WF_RING_RESTART;
+    {
+      unsigned long long* cw = reinterpret_cast<unsigned long long*>(ctl + 16);
+      // relaxed 64-bit atomic loads: fresh values every time, two words per LDS read, broadcast to the wave
+      const unsigned long long w0 = __hip_atomic_load(cw + 0, __ATOMIC_RELAXED, WF_WG), w1 = __hip_atomic_load(cw + 1, __ATOMIC_RELAXED, WF_WG),
+                               w2 = __hip_atomic_load(cw + 2, __ATOMIC_RELAXED, WF_WG), w3 = __hip_atomic_load(cw + 3, __ATOMIC_RELAXED, WF_WG),
+                               w4 = __hip_atomic_load(cw + 4, __ATOMIC_RELAXED, WF_WG), w5 = __hip_atomic_load(cw + 5, __ATOMIC_RELAXED, WF_WG),
+                               w6 = __hip_atomic_load(cw + 6, __ATOMIC_RELAXED, WF_WG);
+      // words 16 + 2r / 17 + 2r tail / head of ring r, 28 live, 29 abort
+      if ((int)(w6 >> 32) != 0) break;  // abort
+      auto fill = [](unsigned long long th) { return (int)((uint32_t)th - (uint32_t)(th >> 32)); };
+      const int readyAvail = __builtin_amdgcn_readfirstlane(fill(w0));
+      const int av[5] = {fill(w1), fill(w2), fill(w3), fill(w4), fill(w5)};  // RESTART, HIT 0..2, NEWITEM
+      int bestAvail = av[0];
+#pragma unroll
+      for (int r = 1; r < 5; ++r)
+        if (av[r] > bestAvail) {
+          bestAvail = av[r];
+          bestRing = WF_RING_RESTART + r;
+        }
+      bestRing = __builtin_amdgcn_readfirstlane(bestRing);
+      bestAvail = __builtin_amdgcn_readfirstlane(bestAvail);
+      // what a swap would move: finished walks out, READY contexts into the lanes without one
+      const int swapGain = nF + (readyAvail < free ? readyAvail : free);
+      if (bestAvail >= 64)
+        pick = W_SERVE;  // a full batch is always worth a step (and feeds READY)
+      else if (swapGain >= a.wfSwapMin)
+        pick = W_SWAP;
+      else if (nP >= a.primMin || (nN == 0 && nP > 0))
+        pick = W_PRIM;
+      else if (nN > 0)
+        pick = W_NODE;
+      else if (swapGain > 0)
+        pick = W_SWAP;
+      else if (bestAvail > 0) {
+        pick = W_SERVE;  // nothing to traverse here and nothing READY: serve what there is
+        serveAtLeast = 1;
+      } else {
+        if (__builtin_amdgcn_readfirstlane((int)w6) <= 0) break;  // every context has retired
+        if (++idleTrips > WF_SPIN_LIMIT) {
+          raiseAbort();
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        prof(7, 0);
+        continue;
+      }
+      idleTrips = 0;
+      if (PROFILE) {
+        pSaw[0]++;
+        (void)readyAvail;
+      }
+    }
+    if (PROFILE) {
+      const unsigned long long now = clock64();
+      pSched += now - pT;
+      pT = now;
+    }
+
+    if (pick == W_PRIM) {
+      const int nNodes = primStep();
+      if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+    } else if (pick == W_NODE) {
+      nodeBurst(nN);
+    } else if (pick == W_SWAP) {
+      swapStep();
+    } else if (pick == W_SERVE) {
+      serveStep(bestRing, serveAtLeast);
+    }
+  }
+  flushProfile();
 }
 
 extern "C" {
-int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream) {
+int srt_launch_render_wf(const RenderArgs* a, int profile, int sweep, int grid, size_t ldsBytes, hipStream_t stream) {
   typedef void (*Kernel)(const RenderArgs);
-  const Kernel k = profile ? srt_render_wf_kernel<false, true>
-                           : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false> : srt_render_wf_kernel<false, false>);
+  const Kernel k = sweep     ? (profile ? srt_render_wf_kernel<false, true, true> : srt_render_wf_kernel<false, false, true>)
+                   : profile ? srt_render_wf_kernel<false, true, false>
+                             : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false, false> : srt_render_wf_kernel<false, false, false>);
   if (ldsBytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return (int)e;

@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 
+from . import abi
 from .abi import SceneBuilder
 from .gltf import load_gltf
 
@@ -140,6 +141,31 @@ def add_masterchief(sb, gltf_path=None):
     return add_model(sb, gltf_path or os.path.join(ASSETS, "masterchief2-separate-xf.gltf"))
 
 
+def scene_masterchief_army(copies=5):
+    """A mesh scene between the reference's own (4 043 nodes: a CU's LDS holds its tree) and the big soups: `copies`
+    instances of the main.cpp mesh side by side (15 210 triangles at 5: what 16-bit primitive references address), with the ground, the
+    light and the metal sphere of the HEAD scene, in one bvhNode.  A tree that is cache-resident, does not fit a CU's LDS
+    and still has 16-bit thread links: what the sweep form of the path-pool kernel is for."""
+    sb = SceneBuilder()
+    first = len(sb.triangles)
+    add_masterchief(sb)
+    base = [t.copy() for t in sb.triangles[first:]]
+    for c in range(1, copies):
+        dx, dz = 2.6 * ((c + 1) // 2) * (1 if c % 2 else -1), -2.5 * (c % 3)
+        for t in base:
+            t2 = t.copy()
+            t2["p"][..., 0] += np.float32(dx)
+            t2["p"][..., 2] += np.float32(dz)
+            sb.triangles.append(t2)
+            sb._add_prims(abi.SRT_PRIM_TRIANGLE, sb._tri_count, len(t2))
+            sb._tri_count += len(t2)
+    _ground(sb)
+    sb.add_sphere((-7.0, 4.0, 6.0), 1.0, sb.light((250.2, 220.9, 110.2)))
+    sb.add_sphere((3.0, 1.0, 3.0), 1.0, sb.metal((0.7, 0.6, 0.5), 0.0))
+    sb.world_bvh(0, None, 0.0, 1.0)
+    return sb
+
+
 def scene_gltf(gltf_path):
     """The `if (0)` / `else` branches of main.cpp:60-79 (square.gltf, scene.gltf, ...): the model's triangles and
     the checker ground in one bvhNode."""
@@ -230,4 +256,4 @@ def scene_sphere_field():
     return sb
 
 
-SCENES = {"spheres": scene_spheres, "iron": scene_iron, "masterchief": scene_masterchief, "sphere_field": scene_sphere_field}
+SCENES = {"army": scene_masterchief_army, "spheres": scene_spheres, "iron": scene_iron, "masterchief": scene_masterchief, "sphere_field": scene_sphere_field}

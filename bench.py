@@ -72,8 +72,7 @@ WORKLOADS = {
     # a tree that is cache-resident but does not fit a CU's LDS (66 k nodes, 2 MB): the 256-thread kernel's regime, bound by
     # the vector-memory address unit (what treelets are for)
     "soup_50k_720p_64spp": ("soup:50000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),
-    # trees that do not fit a CU's LDS but whose references fit the 16-bit thread links (< 32 767 nodes): the sweep form of the
-    # path-pool kernel streams them through LDS in blocks (five copies of the mesh; a 16 k-triangle soup)
+    # (five copies of the mesh: 16.7 k nodes; a 16 k-triangle soup: the 256-thread kernel on trees just beyond a CU's LDS)
     "army_720p_1024spp": ("army", 1280, 720, 1024, 4, "reference", "faithful", "valu-issue"),
     "soup_16k_720p_64spp": ("soup:16000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),
     # HBM-bound points (SURVEY 8d "Synthetic"): the parity path (reference tree, bvh.h order) and the
@@ -574,8 +573,7 @@ def main():
             pmc["_samples"] = samples_per_launch
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        kernel_name = ("srt_render_wf_kernel<false,false,true>" if launch.get("lds_tree_mode") == 4 else
-                       "srt_render_wf_kernel<true,false,false>" if launch.get("lds_tree_mode") == 3 else
+        kernel_name = ("srt_render_wf_kernel<true,false>" if launch.get("lds_tree_mode") == 3 else
                        "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
                                                                    "true" if launch["lds_tree"] else "false",
                                                                    "true" if launch.get("lds_tree_mode") == 2 else "false"))
@@ -594,13 +592,10 @@ def main():
                                                                                      + (" (native communicator unavailable)" if native_note else "")))},
             "device": info,
             "launch": {"workgroups": launch["workgroups"], "threads_per_workgroup": launch["threads"], "lds_bytes_per_workgroup": launch["lds_bytes"],
-                       "node_records": ("streamed through every CU's LDS in blocks, once per sweep" if launch.get("lds_tree_mode") == 4 else
-                                        "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM"),
-                       "kernel_form": ("path pool, sweep form: the threaded tree streamed through LDS block by block (srt_wavefront.hip)"
-                                       if launch.get("lds_tree_mode") == 4 else
-                                       "path pool: lanes traverse, full waves shade contexts from per-class LDS rings (srt_wavefront.hip)"
+                       "node_records": "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM",
+                       "kernel_form": ("path pool: lanes traverse, full waves shade contexts from per-class LDS rings (srt_wavefront.hip)"
                                        if launch.get("lds_tree_mode") == 3 else "step scheduler: one path per lane (srt_kernels.hip)"),
-                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") in (1, 3, 4) else "LDS"},
+                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") in (1, 3) else "LDS"},
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),
         }

@@ -24,7 +24,7 @@
 extern "C" {
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_render_occupancy(int traversal, int count, int ldsTree, size_t ldsBytes, int* blocksPerCU);
-int srt_launch_render_wf(const RenderArgs* a, int profile, int sweep, int grid, size_t ldsBytes, hipStream_t stream);
+int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream);
 int srt_launch_finalize(const SrtFixedAccum* fix, float4* out, int n, int samples, hipStream_t stream);
 int srt_launch_sum_chunks(const float4* buf, float4* out, int n, int chunks, float limit, hipStream_t stream);
 int srt_launch_resolve(const ResolveArgs* a, hipStream_t stream);
@@ -234,7 +234,6 @@ struct Tunables {
   int ldsTree;
   int wavefront, wfPool, wfSwapMin, wfSwapBig, wfProfile;
   int wideNodes, attGlobal;
-  int sweep, wfBlockNodes, wfSweepWaves;
 };
 
 struct SrtContext {
@@ -353,12 +352,6 @@ const TunableName kTunables[] = {
     {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 32},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
     {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},
-    // the sweep form of the path-pool kernel (the threaded tree streamed through LDS in blocks of wf_block_nodes records)
-    // for FAITHFUL scenes whose tree does not fit a CU's LDS but whose references fit the 16-bit thread links (< 32 767
-    // nodes): 1 on, 0 off, 2 = also for trees that would fit (tests)
-    {"sweep", "SRT_SWEEP", &Tunables::sweep, 1},
-    {"wf_block_nodes", "SRT_WF_BLOCK_NODES", &Tunables::wfBlockNodes, 4096},  // 128 KB of tree + 27 KB of rings for 1536 contexts
-    {"wf_sweep_waves", "SRT_WF_SWEEP_WAVES", &Tunables::wfSweepWaves, 8},     // traversal waves of the sweep form (of 16)
     // closest-hit traversal: 128-byte records with four boxes (1, read at srtUploadScene) instead of the 64-byte two-box
     // records (0).  Measured, not faster: the same bytes in half as many, twice as large random requests, at 2 instead
     // of 3 workgroups per CU (three pending references per level) -- profiles/r03/wide_nodes.txt.  Off.
@@ -1276,23 +1269,15 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   // LDS behind the tree: 64 control words, six rings of 16-bit slots, and per context the (t, primitive) its walk ended at:
   // 18 bytes per context.  Ring capacity = pool size = the largest of 1024, 1536, 2048, 3072, 4096 that fits and does not
   // exceed the tunable (the headline scene's 129 KB tree leaves room for 1536).
-  // Sweep form of the same kernel: a FAITHFUL scene whose tree does NOT fit a CU's LDS but has thread links (host-built,
-  // < 32 767 nodes) is streamed through LDS in blocks of wf_block_nodes records (tunable sweep = 2 forces this form on
-  // trees that would fit, for the tests).
-  const bool sweepWanted = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->tun.sweep > 0 && ctx->tun.wavefront > 0 && !p->countStats &&
-                           ctx->scene.nodeThread != nullptr && ctx->scene.primClass != nullptr && ctx->scene.numNodes >= 2 &&
-                           (ctx->tun.sweep >= 2 || (!ldsTree && ctx->tun.ldsTree > 0));
-  const int wfBlockNodes = std::max(64, std::min(std::min(4096, ctx->tun.wfBlockNodes), ctx->scene.numNodes));
   int wfPoolSize = 0, wfRingCap = 0, wfRingShift = 0, wfRingMul3 = 0;
-  const size_t wfFixed = (size_t)(sweepWanted ? wfBlockNodes : ctx->scene.numNodes) * 32 + 64 * sizeof(int32_t);
+  const size_t wfFixed = (size_t)ctx->scene.numNodes * 32 + 64 * sizeof(int32_t);
   {
     // ring counters are 32-bit and a 3 * 2^j ring cannot take their wrap-around: such rings only while a workgroup's
     // enqueues stay far below 2^32 (about three per sample)
     const double enqueuesPerGroup = 4.0 * (double)a.numLocalTiles * SRT_TILE_PIXELS * (double)p->spp / std::max(1, ctx->prop.multiProcessorCount);
     static const struct { int cap, shift, mul3; } kRings[] = {{4096, 12, 0}, {3072, 10, 1}, {2048, 11, 0}, {1536, 9, 1}, {1024, 10, 0}};
     for (const auto& r : kRings) {
-      // (the sweep form takes 1024 rays per sweep and serves the previous sweep's contexts meanwhile: three per lane)
-      if (r.cap > std::max(1024, sweepWanted ? 1536 : ctx->tun.wfPool) || wfFixed + (size_t)18 * r.cap > 160 * 1024) continue;
+      if (r.cap > std::max(1024, ctx->tun.wfPool) || wfFixed + (size_t)18 * r.cap > 160 * 1024) continue;
       if (r.mul3 && enqueuesPerGroup > 2.0e9) continue;
       wfRingCap = r.cap;
       wfRingShift = r.shift;
@@ -1302,13 +1287,12 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     wfPoolSize = wfRingCap;
   }
   const size_t wfLds = wfFixed + (size_t)18 * wfRingCap;
-  const bool sweep = sweepWanted && wfRingCap > 0;
-  const bool wavefront = sweep || (ldsTree && ctx->tun.wavefront > 0 && ctx->scene.numNodes >= ctx->tun.wavefront && !p->countStats && wfRingCap > 0 &&
-                                   ctx->scene.primClass != nullptr);
+  const bool wavefront = ldsTree && ctx->tun.wavefront > 0 && ctx->scene.numNodes >= ctx->tun.wavefront && !p->countStats && wfRingCap > 0 &&
+                         ctx->scene.primClass != nullptr;
   int perCU = 0;
   if (wavefront || srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
-  const int wgWaves = (ldsTree || sweep) ? 16 : 4;
+  const int wgWaves = ldsTree ? 16 : 4;
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * wgWaves - 1) / (SRT_TILE_PIXELS * wgWaves));
   if (grid < 1) grid = 1;
   auto ensure = [&](DeviceBuffer& b, size_t need) -> int {
@@ -1332,8 +1316,6 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfRingCap = wfRingCap;
     a.wfRingShift = wfRingShift;
     a.wfRingMul3 = wfRingMul3;
-    a.wfBlockNodes = wfBlockNodes;
-    a.wfSweepWaves = std::max(1, std::min(15, ctx->tun.wfSweepWaves));
     a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
@@ -1344,11 +1326,11 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (a.stats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 96 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  ctx->lastLaunch[0] = sweep ? 4 : wavefront ? 3 : ldsTreeMode;
+  ctx->lastLaunch[0] = wavefront ? 3 : ldsTreeMode;
   ctx->lastLaunch[1] = grid;
-  ctx->lastLaunch[2] = (ldsTree || sweep) ? 1024 : 256;
+  ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
   ctx->lastLaunch[3] = (int32_t)(wavefront ? wfLds : lds);
-  int rc = wavefront ? srt_launch_render_wf(&a, ctx->tun.wfProfile > 0, sweep, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
+  int rc = wavefront ? srt_launch_render_wf(&a, ctx->tun.wfProfile > 0, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(ctx, hipEventRecord(ctx->evStop, stream));
   ctx->timed = true;

@@ -151,8 +151,6 @@ struct RenderArgs {
   float* wfAttHi;
   int32_t wfPoolSize, wfRingCap, wfSwapMin, wfSwapBig;
   int32_t wfRingShift, wfRingMul3;  // wfRingCap = (wfRingMul3 ? 3 : 1) << wfRingShift
-  int32_t wfBlockNodes;             // sweep form (the tree streamed through LDS): node records per block
-  int32_t wfSweepWaves;             // sweep form: how many of the workgroup's 16 waves traverse (the others serve the rings)
   int32_t* wfError;
 };
 

@@ -67,15 +67,8 @@ __device__ __forceinline__ uint32_t bufLoad1(Rsrc r, int off) { return __builtin
 // SINGLE: the world list is one tree (as in srt_render_kernel).  PROFILE (tunable wf_profile, tools/wf_profile.py): per
 // step kind, the clocks the waves spent in it, its executions and the lanes they served -> RenderArgs::stats[32 + ...]
 // (kinds: 0 node visit, 1 primitive test, 2 swap, 3-5 hit step per class, 6 restart, 7 idle, 8 lost claim, 9 item pull).
-// SWEEP: the tree does NOT fit a CU's LDS (up to 32 766 nodes: what the 16-bit thread links address).  In the threaded
-// pre-order tree a walk's node index only ever grows -- a hit goes to the next record, a miss to a later one -- so a ray
-// sweeps through the node array once, left to right, and the workgroup can stream the array through LDS in blocks of
-// RenderArgs::wfBlockNodes records: barrier, copy block b in, barrier, every lane whose walk stands inside the block
-// advances until it leaves it (lanes further on wait, nobody is ever behind), next block.  Between sweeps the workgroup
-// hands the finished walks to the rings, serves the rings empty in barrier-separated rounds (full waves, one class per
-// hit step, as above) and takes READY contexts for the next sweep.  Same records, same arithmetic, same bits.
 #define WF_PROF_KINDS 10
-template <bool SINGLE, bool PROFILE, bool SWEEP>
+template <bool SINGLE, bool PROFILE>
 __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const RenderArgs a) {
 
   constexpr int32_t DONE = (int32_t)0xFFFF8000;       // the 16-bit "no reference", sign-extended
@@ -83,7 +76,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   extern __shared__ int32_t lds[];
   const DevScene& sc = a.scene;
   char* const ldsTree = reinterpret_cast<char*>(lds);
-  const int treeBytes = (SWEEP ? a.wfBlockNodes : sc.numNodes) * 32;
+  const int treeBytes = sc.numNodes * 32;
   int32_t* const ctl = reinterpret_cast<int32_t*>(ldsTree + treeBytes);
   const int RCAP = a.wfRingCap, POOL = a.wfPoolSize;
   uint16_t* const ringSlots = reinterpret_cast<uint16_t*>(ctl + WF_CTL_WORDS);
@@ -118,7 +111,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   // ---- set-up: the threaded tree into LDS (as srt_render_kernel LDSTREE), empty rings, every context waits for an item
   {
     float4* dst = reinterpret_cast<float4*>(ldsTree);
-    for (int i = threadIdx.x; i < (SWEEP ? 0 : sc.numNodes * 2); i += WF_BLOCK) {
+    for (int i = threadIdx.x; i < sc.numNodes * 2; i += WF_BLOCK) {
       float4 v = bufLoad4(rsNodes, 16 * i);
       const int r = __float_as_int(v.w);
       if (i & 1)
@@ -235,9 +228,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   ray.time = 0.0f;
   float closest = SRT_INF, rayA = 0.0f, slabTol = SRT_INF;
   V3 rcpD = mk(0.0f, 0.0f, 0.0f), negOR = mk(0.0f, 0.0f, 0.0f);
-  // SWEEP: the block of the node array that is in LDS: records [blkLo, blkHi).  A walk never stands before it.
-  int blkLo = 0, blkHi = SWEEP ? 0 : 0x7fffffff;
-  auto atNode = [&]() { return SWEEP ? (uint32_t)cur < (uint32_t)blkHi : cur >= 0; };  // at a node whose record is in LDS
+  auto atNode = [&]() { return cur >= 0; };
   auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)DONE; };
   auto popNext = [&]() {
     int next = (int32_t)(int16_t)link;
@@ -349,7 +340,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           pLanes[0] += __popcll(__ballot(atNode()));
         }
         if (atNode()) {
-          const char* rec = ldsTree + ((cur - (SWEEP ? blkLo : 0)) << 5);
+          const char* rec = ldsTree + (cur << 5);
           const float4 n0 = *reinterpret_cast<const float4*>(rec);
           const float4 n1 = *reinterpret_cast<const float4*>(rec + 16);
           bool undecided;
@@ -672,142 +663,6 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 2 + k], pSaw[k]);
     }
   };
-  if (SWEEP) {
-    // ================================================= the tree streamed through LDS, block by block
-    // Two roles, fixed per wave for the launch.  TRAVERSAL waves (the first a.wfSweepWaves of the sixteen) move in step
-    // through the blocks: a barrier of their own (an LDS counter: the servers never take part), copy block b in, barrier,
-    // advance their lanes inside it; at the end of a sweep they hand the finished walks to the rings and take READY
-    // contexts.  SERVER waves serve the rings all the time (full batches; partial ones when READY runs low), so that
-    // shading overlaps with the sweeps instead of stretching every block step.
-    const int BN = a.wfBlockNodes, NB = (sc.numNodes + BN - 1) / BN;
-    const int wavesT = a.wfSweepWaves, waveId = threadIdx.x >> 6;
-    int32_t* const bar = &ctl[30];  // arrivals of the traversal waves' barrier (monotone); ctl[31]: 1 = the traversal waves have left
-    auto ringFill = [&](int r) -> int {
-      const unsigned long long th = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&ctl[WF_CTL_TAIL(r)]), __ATOMIC_RELAXED, WF_WG);
-      return __builtin_amdgcn_readfirstlane((int)((uint32_t)th - (uint32_t)(th >> 32)));
-    };
-    auto word = [&](int i) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[i], __ATOMIC_RELAXED, WF_WG)); };
-    if (waveId >= wavesT) {
-      // ---------------------------------------------- a server wave
-      for (int idle = 0;;) {
-        if (word(WF_CTL_ABORT) != 0) break;
-        const bool hungry = ringFill(WF_RING_READY) < 64 * wavesT;  // the traversal waves will run short: partial batches too
-        bool did = false;
-        for (int r = WF_RING_RESTART; r < WF_RINGS && !did; ++r) {
-          const int n = ringFill(r);
-          if (n >= 64 || (hungry && n > 0)) did = serveStep(r, n >= 64 ? 64 : 1) > 0;
-        }
-        if (did) {
-          idle = 0;
-          continue;
-        }
-        if (word(WF_CTL_LIVE) <= 0 || word(31) != 0) break;  // every context has retired / the traversal waves are gone
-        if (++idle > WF_SPIN_LIMIT) {
-          raiseAbort();
-          break;
-        }
-        __builtin_amdgcn_s_sleep(16);
-        prof(7, 0);
-      }
-      flushProfile();
-      return;
-    }
-    // ---------------------------------------------- a traversal wave
-    int epoch = 0;
-    bool gaveUp = false;
-    auto travBarrier = [&]() {  // all traversal waves; what they wrote to LDS before is visible after
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, WF_WG);
-      epoch++;
-      for (int spins = 0; word(30) - epoch * wavesT < 0;) {
-        if (++spins > WF_SPIN_LIMIT || word(WF_CTL_ABORT) != 0) {
-          raiseAbort();
-          gaveUp = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    auto retireStep = [&]() {  // finished walks -> rings (a swap without the taking)
-      const bool fin = cur == DONE && path >= 0;
-      const bool hit = fin && hitRef != DONE;
-      int cls = 0;
-      if (hit) {
-        cls = (int)__builtin_amdgcn_raw_buffer_load_b8(rsClass, ~hitRef, 0, 0);
-        __hip_atomic_store(&hitT[path], closest, __ATOMIC_RELAXED, WF_WG);
-        __hip_atomic_store(&hitPrim[path], (uint16_t)hitRef, __ATOMIC_RELAXED, WF_WG);
-      }
-      asm volatile("" ::: "memory");
-      enqueue(!fin ? -1 : (hit ? WF_RING_HIT + cls : WF_RING_RESTART), path);
-      if (fin) {
-        path = -1;
-        hitRef = DONE;
-      }
-    };
-    for (;;) {
-      // ---- every walk of the last sweep is over: contexts out, READY contexts in
-      retireStep();
-      {
-        int id = -1;
-        claim(WF_RING_READY, ~0ull, 64, 1, id);
-        if (PROFILE) {
-          pSaw[0]++;                                   // sweeps
-          pSaw[1] += __popcll(__ballot(id >= 0));      // rays taken
-        }
-        if (id >= 0) {
-          const float4 A = bufLoad4(rsPool, id << 7), B = bufLoad4(rsPool, (id << 7) + 16);
-          ray.o = mk(A.x, A.y, A.z);
-          ray.d = mk(B.x, B.y, B.z);
-          ray.time = A.w;
-          path = id;
-          startTraversal();
-        }
-      }
-      // ---- do the traversal waves go on?  Wave 0 decides between two barriers, so that all of them read the same word:
-      // on while a context is alive (a wave without rays sweeps along, which costs a few microseconds, and asks again)
-      prof(2, 0);  // hand-over + taking
-      travBarrier();
-      if (waveId == 0 && lane == 0)
-        __hip_atomic_store(&ctl[31], (word(WF_CTL_LIVE) <= 0 || word(WF_CTL_ABORT) != 0) ? 1 : 0, __ATOMIC_RELAXED, WF_WG);
-      travBarrier();
-      prof(8, 0);  // the two barriers of the go / stop decision
-      if (word(31) != 0 || gaveUp) break;
-      // ---- the sweep
-      for (int blk = 0; blk < NB && !gaveUp; ++blk) {
-        travBarrier();  // everybody is done with the block that is in LDS
-        prof(7, 0);     // waiting for the slowest traversal wave
-        blkLo = blk * BN;
-        blkHi = min(sc.numNodes, blkLo + BN);
-        float4* dst = reinterpret_cast<float4*>(ldsTree);
-        for (int i = threadIdx.x; i < (blkHi - blkLo) * 2; i += wavesT * 64) {
-          const int g = 2 * blkLo + i;
-          float4 v = bufLoad4(rsNodes, 16 * g);
-          const int r = __float_as_int(v.w);
-          if (g & 1)
-            v.w = __int_as_float(sc.nodeThread[g >> 1]);
-          else if (r >= 0)
-            v.w = __int_as_float(r >> 5);
-          dst[i] = v;
-        }
-        travBarrier();
-        prof(9, 0);  // block copy (+ its barrier)
-        for (;;) {  // this wave's lanes inside the block, and those at primitives, until none is left
-          const int nN = __popcll(__ballot(atNode())), nP = __popcll(__ballot(atPrim()));
-          if (nN + nP == 0) break;
-          if (nP >= a.primMin || nN == 0) {
-            const int nNodes = primStep();
-            if (nNodes >= a.fuseMin) nodeBurst(nNodes);
-          } else {
-            nodeBurst(nN);
-          }
-        }
-      }
-      blkHi = 0;  // nothing is at a node now: every walk is over
-    }
-    flushProfile();
-    return;
-  }
   for (;;) {
     // ---- traverse for as long as the rings need no look: a tight loop of node bursts and primitive steps.  The rings are
     // looked at (below) when this wave has lanes to refill, nothing to traverse, or every fourth pass: with sixteen waves
@@ -906,11 +761,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
 }
 
 extern "C" {
-int srt_launch_render_wf(const RenderArgs* a, int profile, int sweep, int grid, size_t ldsBytes, hipStream_t stream) {
+int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream) {
   typedef void (*Kernel)(const RenderArgs);
-  const Kernel k = sweep     ? (profile ? srt_render_wf_kernel<false, true, true> : srt_render_wf_kernel<false, false, true>)
-                   : profile ? srt_render_wf_kernel<false, true, false>
-                             : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false, false> : srt_render_wf_kernel<false, false, false>);
+  const Kernel k = profile ? srt_render_wf_kernel<false, true>
+                           : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false> : srt_render_wf_kernel<false, false>);
   if (ldsBytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return (int)e;

@@ -290,11 +290,10 @@ class Context:
 
     def launch_info(self):
         """The most recent render launch (include/srt_hip_test.h).  lds_tree_mode: 0 node records through the L1,
-        1 / 2 LDS-resident tree with the attenuation stacks in global memory / LDS, 3 the path-pool kernel, 4 its sweep form
-        (the tree streamed through LDS in blocks)."""
+        1 / 2 LDS-resident tree with the attenuation stacks in global memory / LDS, 3 the path-pool kernel."""
         out = np.zeros(4, np.int32)
         self._check(lib.srtGetLaunchInfo(self.h, out.ctypes.data))
-        return {"lds_tree": int(out[0]) in (1, 2, 3), "lds_tree_mode": int(out[0]), "wavefront": int(out[0]) in (3, 4), "sweep": int(out[0]) == 4, "workgroups": int(out[1]),
+        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "wavefront": int(out[0]) == 3, "workgroups": int(out[1]),
                 "threads": int(out[2]), "lds_bytes": int(out[3])}
 
     def last_kernel_ms(self):

@@ -145,7 +145,7 @@ def scene_masterchief_army(copies=5):
     """A mesh scene between the reference's own (4 043 nodes: a CU's LDS holds its tree) and the big soups: `copies`
     instances of the main.cpp mesh side by side (15 210 triangles at 5: what 16-bit primitive references address), with the ground, the
     light and the metal sphere of the HEAD scene, in one bvhNode.  A tree that is cache-resident, does not fit a CU's LDS
-    and still has 16-bit thread links: what the sweep form of the path-pool kernel is for."""
+    and still has 16-bit thread links: the 256-thread kernel's regime (bench.py army_720p_1024spp; profiles/r03/sweep_form.txt)."""
     sb = SceneBuilder()
     first = len(sb.triangles)
     add_masterchief(sb)

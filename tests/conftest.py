@@ -54,20 +54,16 @@ def camera(dev, abi):
     return dev.make_camera(abi.default_camera_params())
 
 
-@pytest.fixture(params=["wavefront", "sweep", "lds_tree", "l1_nodes"])
+@pytest.fixture(params=["wavefront", "lds_tree", "l1_nodes"])
 def node_path(request, ctx):
     """The three forms of the FAITHFUL render kernel: the path-pool kernel (srt_wavefront.hip: lanes traverse the
     LDS-resident threaded tree, full waves shade contexts taken from per-class rings; the default for scenes whose node
     array fits a CU's LDS), the step-scheduler kernel over the same LDS-resident tree (tunable wavefront = 0), and the
     256-thread step-scheduler kernel that reads the node records through the vector L1 (lds_tree = 0; what larger
-    scenes get).  "sweep" is the path-pool kernel's form for trees that do NOT fit a CU's LDS (the threaded tree streamed
-    through LDS in blocks), forced here onto every scene with blocks of 1 024 records, so that the mesh scenes cross
-    block boundaries.  A counting launch (count_stats) of the first two runs the third: the counters belong to the scene."""
-    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront", "sweep", "wf_block_nodes")}
+    scenes get).  A counting launch (count_stats) of the first runs the second: the counters belong to the scene."""
+    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront")}
     ctx.set_tunable("lds_tree", 0 if request.param == "l1_nodes" else 1)  # 1: every tree that fits, however small
-    ctx.set_tunable("wavefront", 1 if request.param in ("wavefront", "sweep") else 0)
-    ctx.set_tunable("sweep", 2 if request.param == "sweep" else 0)
-    ctx.set_tunable("wf_block_nodes", 1024)
+    ctx.set_tunable("wavefront", 1 if request.param == "wavefront" else 0)
     yield request.param
     for k, v in saved.items():
         ctx.set_tunable(k, v)
@@ -77,13 +73,12 @@ def render_counted(ctx, p, node_path):
     """ctx.render_image(p) for a test that also reads ctx.stats(): the image comes from the kernel under test, the
     counters from the counting variant.  For the path-pool kernel these are two launches (its counting variant is the
     step-scheduler kernel over the same tree), and the image is checked to come from the path-pool kernel itself."""
-    if node_path not in ("wavefront", "sweep") or not p.countStats:
+    if node_path != "wavefront" or not p.countStats:
         return ctx.render_image(p)
     p.countStats = 0
     acc, rgba = ctx.render_image(p)
     info = ctx.launch_info()
     assert info["wavefront"] or not info["lds_tree"], info  # a world without a tree (or with one that does not fit) has no LDS-resident form
-    assert info["sweep"] == (node_path == "sweep") or not info["wavefront"], info
     p.countStats = 1
     ctx.render_image(p)
     return acc, rgba

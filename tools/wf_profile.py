@@ -7,8 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 srt = importlib.import_module("sexy-raytracer_amd")
 abi, dev = srt.abi, srt.device()
-scene = sys.argv[1] if len(sys.argv) > 1 else "masterchief"  # SRT_SWEEP=2 SRT_WF_BLOCK_NODES=1024: the sweep form (swap = hand-over +
-# taking, idle = waiting for the slowest traversal wave, lost_claim = go / stop barriers, new_item also holds the block copies)
+scene = sys.argv[1] if len(sys.argv) > 1 else "masterchief"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1280, 720)
 mb = 8 if scene in ("spheres", "sphere_field") else 4

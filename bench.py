@@ -182,8 +182,8 @@ def cpu_baseline(sb, cam_params, abi, width, height, spp_full, max_bounce, seed,
 def kernel_source_id():
     """Identifies the kernel build the counters belong to: hash of the kernel sources and build flags."""
     h = hashlib.sha256()
-    for rel in ("sexy-raytracer_amd/csrc/srt_kernels.hip", "sexy-raytracer_amd/csrc/srt_device.h",
-                "sexy-raytracer_amd/csrc/Makefile"):
+    for rel in ("sexy-raytracer_amd/csrc/srt_kernels.hip", "sexy-raytracer_amd/csrc/srt_wavefront.hip", "sexy-raytracer_amd/csrc/srt_path.h",
+                "sexy-raytracer_amd/csrc/srt_device.h", "sexy-raytracer_amd/csrc/Makefile"):
         try:
             h.update(open(os.path.join(ROOT, rel), "rb").read())
         except OSError:

@@ -26,6 +26,18 @@ __global__ void k(float* out, int iters, long long* cyc) {
     if (OP == 9) { REP16(asm volatile("v_mul_f64 %0, %0, %1\n v_add_f64 %1, %1, %2\n v_floor_f64 %2, %2\n v_cvt_f64_f32 %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0));) }
     if (OP == 10) { unsigned long long w0 = u0, w1 = u1; REP16(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n v_mad_u64_u32 %0, vcc, %2, %2, %0\n v_mad_u64_u32 %1, vcc, %3, %3, %1" : "+v"(w0), "+v"(w1) : "v"(u2), "v"(u3) : "vcc");) u0 ^= (uint32_t)w0 ^ (uint32_t)(w1 >> 32); }
     if (OP == 11) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %1, %1, %0, %0\n v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %1, %1, %0, %0" : "+v"(d0), "+v"(d1));) }
+    if (OP == 13) { REP16(asm volatile("v_min_f32 %0, %0, %1\n v_min_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_min_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 14) { REP16(asm volatile("v_min3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_min3_f32 %2, %2, %3, %0\n v_max3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 15) { REP16(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 16) { REP16(asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 17) { REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");) }
+    if (OP == 18) { REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");) }
+    if (OP == 19) { REP16(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+    if (OP == 20) { REP16(asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n v_pk_add_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0" : "+v"(d0), "+v"(d1));) }
+    if (OP == 21) { REP16(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_min_f32 %1, %1, %2\n v_fma_f32 %2, %2, %3, %0\n v_max_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 22) { REP16(asm volatile("v_fma_f32 %0, %0, %1, %2\n s_nop 0\n v_fma_f32 %1, %1, %2, %3\n s_nop 0\n v_fma_f32 %2, %2, %3, %0\n s_nop 0\n v_fma_f32 %3, %3, %0, %1\n s_nop 0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 23) { REP16(asm volatile("v_med3_f32 %0, %0, %1, %2\n v_med3_f32 %1, %1, %2, %3\n v_med3_f32 %2, %2, %3, %0\n v_med3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    if (OP == 24) { REP16(asm volatile("v_fma_f32 %0, %4, %1, %2\n v_fma_f32 %1, %4, %2, %3\n v_fma_f32 %2, %4, %3, %0\n v_fma_f32 %3, %4, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(iters));) }
     if (OP == 12) { REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %1, %2\n v_min3_f32 %2, %2, %3, %0\n v_max_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");) }
   }
   long long t1 = clock64();
@@ -56,8 +68,10 @@ void run(const char* name, float* out, long long* cyc, int blocksPerCU) {
 int main() {
   float* out; long long* cyc;
   hipMalloc(&out, 256 * 8 * 256 * sizeof(float)); hipMalloc(&cyc, 256 * 8 * 8);
-  for (int b : {1, 5}) {
-#define R(op, name) if (b == 1) run<op>(name, out, cyc, 1); else run<op>(name, out, cyc, 5);
+  for (int b : {1, 4, 5, 8}) {
+#define R(op, name) run<op>(name, out, cyc, b);
+    R(13, "v_min_f32") R(14, "v_min3/max3_f32") R(15, "v_add_f32") R(16, "v_mul_f32") R(17, "v_cmp_lt_f32 -> vcc") R(18, "v_cndmask_b32") R(19, "v_add_u32")
+    R(20, "v_pk_add/mul_f32") R(21, "fma/min/fma/max") R(22, "v_fma_f32 + s_nop 0") R(23, "v_med3_f32") R(24, "v_fma_f32 (one SGPR operand)")
     R(0, "v_fma_f32") R(12, "cndmask/cmp/min3/max") R(7, "xor/shift/alignbit/add") R(1, "v_mul_lo_u32") R(2, "v_mul_hi_u32") R(10, "v_mad_u64_u32")
     R(6, "v_mul_u32_u24") R(3, "v_fma_f64") R(9, "mul/add/floor/cvt f64") R(4, "v_rcp_f32") R(5, "v_sqrt_f32") R(8, "div_scale/fmas/fixup/cvt") R(11, "v_pk_fma_f32")
   }

@@ -573,7 +573,8 @@ def main():
             pmc["_samples"] = samples_per_launch
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        kernel_name = ("srt_render_wf_kernel<true,false>" if launch.get("lds_tree_mode") == 3 else
+        mode = launch.get("lds_tree_mode")
+        kernel_name = ("srt_render_wf_kernel<false,false,true>" if mode == 4 else "srt_render_wf_kernel<true,false,false>" if mode == 3 else
                        "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
                                                                    "true" if launch["lds_tree"] else "false",
                                                                    "true" if launch.get("lds_tree_mode") == 2 else "false"))
@@ -592,10 +593,11 @@ def main():
                                                                                      + (" (native communicator unavailable)" if native_note else "")))},
             "device": info,
             "launch": {"workgroups": launch["workgroups"], "threads_per_workgroup": launch["threads"], "lds_bytes_per_workgroup": launch["lds_bytes"],
-                       "node_records": "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM",
+                       "node_records": ("the tree's top (largest boxes) in every CU's LDS, the rest through the vector L1 / L2" if mode == 4 else
+                                        "LDS-resident (whole node array in every CU's LDS)" if launch["lds_tree"] else "through the vector L1 / L2 / HBM"),
                        "kernel_form": ("path pool: lanes traverse, full waves shade contexts from per-class LDS rings (srt_wavefront.hip)"
-                                       if launch.get("lds_tree_mode") == 3 else "step scheduler: one path per lane (srt_kernels.hip)"),
-                       "attenuation_stacks": "global memory" if launch.get("lds_tree_mode") in (1, 3) else "LDS"},
+                                       + (", hybrid form" if mode == 4 else "") if mode in (3, 4) else "step scheduler: one path per lane (srt_kernels.hip)"),
+                       "attenuation_stacks": "global memory" if mode in (1, 3, 4) else "LDS"},
             "roofline": roofline_block(bound, pmc, pmc_source, avg_kernel_ms, bytes_per_launch, bytes_per_sample, st, info,
                                        scene_footprint, kernel_name),
         }

@@ -42,16 +42,19 @@ int srtRenderAov(SrtContext* ctx, const SrtRenderParams* p, int32_t depth, SrtAo
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10);
 
 /* Step profile of the most recent launch of the path-pool kernel's profiling variant (tunable "wf_profile" = 1;
- * csrc/srt_wavefront.hip): out40 = { clocks[10], executions[10], lanes[10] } for the step kinds node visit, primitive
- * test, swap, hit step of class 0 / 1 / 2, restart, idle, lost claim, item pull; scheduling clocks, total wave clocks; then
- * what the scheduling decisions that looked at the rings saw, summed: decisions, lanes at nodes / at primitives / finished /
- * idle, READY fill, fill of the fullest served ring, RESTART fill. */
-int srtGetWfProfile(SrtContext* ctx, uint64_t* out40);
+ * csrc/srt_wavefront.hip): out46 = { clocks[12], executions[12], lanes[12] } for the step kinds node visit, primitive
+ * test, swap, hit step of class 0 / 1 / 2, restart, idle, lost claim, item pull, visit of a node outside LDS (hybrid form:
+ * the clocks are the wait for the records plus the visit), unused; scheduling clocks, total wave clocks; then what the
+ * scheduling decisions that looked at the rings saw, summed: decisions, lanes at nodes / at primitives / finished / idle,
+ * READY fill, fill of the fullest served ring, RESTART fill. */
+int srtGetWfProfile(SrtContext* ctx, uint64_t* out46);
 
 /* The most recent render-kernel launch: out4 = { 0 node records through the L1, 1 the step-scheduler kernel over the
  * LDS-resident threaded tree (FAITHFUL, node array small enough for a CU's LDS; tunable "lds_tree" = 0 switches it
  * off), 2 the same with the attenuation stacks in LDS as well, 3 the path-pool kernel over the same tree (tunable
- * "wavefront" = 0 switches it off); workgroups; threads per workgroup; LDS bytes per workgroup }. */
+ * "wavefront" = 0 switches it off), 4 the path-pool kernel's hybrid form for a tree that does not fit (its top in LDS, the
+ * rest read from global memory; tunable "wf_hybrid" = 0 switches it off, "wf_resident_max" caps the resident nodes -- both
+ * are read by srtUploadScene); workgroups; threads per workgroup; LDS bytes per workgroup }. */
 int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4);
 
 /* Per-context diagnostic tunables of the work distribution and the wave scheduler ("queues", "unit_tiles",

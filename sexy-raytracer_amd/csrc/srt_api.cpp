@@ -15,6 +15,7 @@
 #include <cstring>
 #include <exception>
 #include <limits>
+#include <queue>
 #include <random>
 #include <string>
 #include <vector>
@@ -234,6 +235,7 @@ struct Tunables {
   int ldsTree;
   int wavefront, wfPool, wfSwapMin, wfSwapBig, wfProfile;
   int wideNodes, attGlobal;
+  int wfHybrid, wfResidentMax, wfFarRounds;
 };
 
 struct SrtContext {
@@ -351,14 +353,23 @@ const TunableName kTunables[] = {
     {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 2048},       // path contexts per workgroup (1024 lanes traverse)
     {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 32},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
-    {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},
+    {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
     // closest-hit traversal: 128-byte records with four boxes (1, read at srtUploadScene) instead of the 64-byte two-box
     // records (0).  Measured, not faster: the same bytes in half as many, twice as large random requests, at 2 instead
     // of 3 workgroups per CU (three pending references per level) -- profiles/r03/wide_nodes.txt.  Off.
     {"wide_nodes", "SRT_WIDE_NODES", &Tunables::wideNodes, 0},
     // closest-hit traversal of trees with at least this many nodes: attenuation stacks in global memory (4 instead of 3
     // workgroups per CU); 0 = never.  +3 % at 4 M triangles, -5 % at 10 M (same file).  Off.
-    {"att_global", "SRT_ATT_GLOBAL", &Tunables::attGlobal, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
+    {"att_global", "SRT_ATT_GLOBAL", &Tunables::attGlobal, 0},
+    // path-pool kernel over a tree that does not fit into LDS: its top (the boxes with the largest surface, closed upward)
+    // stays in LDS, the rest is read from global memory (srt_wavefront.hip HYBRID).  wf_hybrid 0 = never (such scenes run
+    // the 256-thread kernel); wf_resident_max > 0 caps the resident nodes, which also sends trees that WOULD fit down
+    // this path (the parity tests set it to a few dozen).  Both are read at srtUploadScene.
+    {"wf_hybrid", "SRT_WF_HYBRID", &Tunables::wfHybrid, 1},
+    {"wf_resident_max", "SRT_WF_RESIDENT_MAX", &Tunables::wfResidentMax, 0},
+    // hybrid form: node visits per round (srt_wavefront.hip); 0 = 2 when at least a fifth of the nodes is resident, else 1
+    // (profiles/r03/hybrid.txt)
+    {"wf_far_rounds", "SRT_WF_FAR_ROUNDS", &Tunables::wfFarRounds, 0},
 };
 
 size_t ldsBytesFor(const SrtContext* ctx, int maxBounce, int stackDepth, bool attGlobal = false) {
@@ -894,12 +905,120 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
     }
     if (!ok) nodeThread.clear();
   }
+  // ---- path-pool kernel, hybrid form (srt_wavefront.hip HYBRID): threaded records with 32-bit references, renumbered so
+  // that the RESIDENT nodes come first.  Resident = the wfResident boxes of largest surface area reachable from the roots
+  // (a child's box lies inside its parent's, so the set is closed upward: a walk leaves LDS once per excursion and comes
+  // back through a thread link).  Inside each group the order is the trees' pre-order.
+  // Record = (bmin.xyz, reference taken on a box hit) (bmax.xyz, link), node references = new indices, link = successor
+  // << 2 | what follows a leaf's FIRST object: 0 nothing (a single-object leaf), 1 the next primitive of the same array
+  // (reference - 2: the leaves' triangles are neighbours in tree order, above), 2 primSecond[~first] (any other pair).
+  // Successor = where the walk goes when this node's subtree is done: a node index or kDoneW.  Same trees as nodeThread:
+  // host-built, every node's children two nodes or two primitives -- but no 15-bit limit.
+  std::vector<float4> nodesWf;
+  std::vector<int32_t> worldWf, primSecond;
+  int32_t wfResident = 0;
+  if (ctx->tun.wfHybrid > 0 && !nodes.empty()) {
+    const size_t n = nodes.size() / 2;
+    const size_t fits = (160 * 1024 - 64 * sizeof(int32_t) - 20 * 2048) / 32;       // beside a pool of 2048 contexts
+    const size_t fitsWhole = (160 * 1024 - 64 * sizeof(int32_t) - 18 * 1024) / 32;  // the whole-tree form's smallest pool
+    const size_t cap = ctx->tun.wfResidentMax > 0 ? std::min<size_t>(fits, (size_t)ctx->tun.wfResidentMax) : fits;
+    const int32_t kDoneW = -(1 << 29);
+    auto refOf = [&](size_t slot) {
+      int32_t r;
+      memcpy(&r, &nodes[slot].w, 4);
+      return r;
+    };
+    bool ok = n > (ctx->tun.wfResidentMax > 0 ? cap : fitsWhole) && n < ((size_t)1 << 28) &&
+              (int64_t)d->numTriangles < (1 << 27) && (int64_t)d->numSpheres < (1 << 27);
+    for (const auto& dt : ctx->itemDeviceTree) ok = ok && dt.base < 0;
+    for (size_t i = 0; ok && i < n; ++i) ok = (refOf(2 * i) >= 0) == (refOf(2 * i + 1) >= 0);
+    // successor of every node (original indices, -1 = done), pre-order of the world's trees
+    std::vector<int32_t> succ, preorder;
+    if (ok) {
+      succ.assign(n, -2);
+      preorder.reserve(n);
+      std::vector<std::pair<int32_t, int32_t>> todo;
+      for (auto it = world.rbegin(); it != world.rend(); ++it)
+        if (*it >= 0) todo.emplace_back(SRT_NODE_INDEX(*it), -1);
+      while (ok && !todo.empty()) {
+        const auto [i, after] = todo.back();
+        todo.pop_back();
+        if (i < 0 || (size_t)i >= n || succ[i] != -2) {  // a node reached twice is not a tree: leave it to the stack walk
+          ok = false;
+          break;
+        }
+        succ[i] = after;
+        preorder.push_back(i);
+        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
+        if (l >= 0) {
+          todo.emplace_back(SRT_NODE_INDEX(r), after);             // the right subtree is followed by this node's successor
+          todo.emplace_back(SRT_NODE_INDEX(l), SRT_NODE_INDEX(r));  // the left subtree by the right child
+        }
+      }
+    }
+    if (ok && !preorder.empty()) {
+      auto area = [&](size_t i) {
+        const float4 &lo = nodes[2 * i], &hi = nodes[2 * i + 1];
+        const double x = (double)hi.x - lo.x, y = (double)hi.y - lo.y, z = (double)hi.z - lo.z;
+        const double s2 = x * y + y * z + z * x;
+        return s2 == s2 ? s2 : 1e300;  // a NaN box is visited like any other: keep it near the top
+      };
+      std::vector<uint8_t> resident(n, 0);
+      std::priority_queue<std::pair<double, int32_t>> open;
+      for (int32_t wr : world)
+        if (wr >= 0) open.emplace(area((size_t)SRT_NODE_INDEX(wr)), -SRT_NODE_INDEX(wr));  // ties: the lower index first
+      size_t k = 0;
+      while (k < cap && !open.empty()) {
+        const int32_t i = -open.top().second;
+        open.pop();
+        resident[i] = 1;
+        ++k;
+        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
+        if (l >= 0) {
+          open.emplace(area((size_t)SRT_NODE_INDEX(l)), -SRT_NODE_INDEX(l));
+          open.emplace(area((size_t)SRT_NODE_INDEX(r)), -SRT_NODE_INDEX(r));
+        }
+      }
+      wfResident = (int32_t)k;
+      std::vector<int32_t> newIndex(n, -1);
+      int32_t nextRes = 0, nextGlob = wfResident;
+      for (int32_t i : preorder) newIndex[i] = resident[i] ? nextRes++ : nextGlob++;
+      for (size_t i = 0; i < n; ++i)
+        if (newIndex[i] < 0) newIndex[i] = nextGlob++;  // not part of any tree of the world list: never visited
+      primSecond.assign((size_t)2 * std::max(d->numTriangles, d->numSpheres) + 2, kDoneW);
+      nodesWf.resize(2 * n);
+      for (size_t i = 0; i < n; ++i) {
+        float4 lo = nodes[2 * i], hi = nodes[2 * i + 1];
+        const int32_t l = refOf(2 * i), r = refOf(2 * i + 1);
+        const int32_t after = succ[i] >= 0 ? newIndex[succ[i]] : kDoneW;  // (-2, an unreachable node: never read)
+        int32_t taken = l, flag = 0;
+        if (l >= 0) {
+          taken = newIndex[SRT_NODE_INDEX(l)];
+        } else if (r != l) {
+          if (r == l - 2 && ((~l) & 1) == ((~r) & 1)) {
+            flag = 1;
+          } else {
+            flag = 2;
+            primSecond[(size_t)~l] = r;
+          }
+        }
+        const int32_t link = (int32_t)((uint32_t)after << 2) | flag;
+        memcpy(&lo.w, &taken, 4);
+        memcpy(&hi.w, &link, 4);
+        nodesWf[2 * (size_t)newIndex[i]] = lo;
+        nodesWf[2 * (size_t)newIndex[i] + 1] = hi;
+      }
+      for (int32_t wr : world) worldWf.push_back(wr >= 0 ? newIndex[SRT_NODE_INDEX(wr)] : wr);
+    }
+  }
   std::vector<uint8_t> primClass((size_t)2 * std::max(d->numTriangles, d->numSpheres) + 2, 2);
   for (int i = 0; i < d->numTriangles; ++i) primClass[(size_t)i << 1] = classOf(triShade[4 * (size_t)i + 3].w, false);
   for (int i = 0; i < d->numSpheres; ++i) primClass[((size_t)i << 1) | 1] = classOf(spheres[3 * (size_t)i + 1].w, true);
   DevScene& s = ctx->scene;
   memset(&s, 0, sizeof s);
   if (!nodeThread.empty() && uploadVec(ctx, nodeThread, &s.nodeThread)) return 1;
+  if (!nodesWf.empty() && (uploadVec(ctx, nodesWf, &s.nodesWf) || uploadVec(ctx, worldWf, &s.worldWf) || uploadVec(ctx, primSecond, &s.primSecond))) return 1;
+  s.wfResident = wfResident;
   if (uploadVec(ctx, primClass, &s.primClass, 16)) return 1;
   s.numPrimClass = (int32_t)primClass.size();
   if (uploadVec(ctx, nodeAxis, &s.nodeAxis, 64) || uploadVec(ctx, nodes, &s.nodes) || uploadVec(ctx, triTest, &s.triTest) || uploadVec(ctx, triShade, &s.triShade) ||
@@ -1270,14 +1389,19 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   // 18 bytes per context.  Ring capacity = pool size = the largest of 1024, 1536, 2048, 3072, 4096 that fits and does not
   // exceed the tunable (the headline scene's 129 KB tree leaves room for 1536).
   int wfPoolSize = 0, wfRingCap = 0, wfRingShift = 0, wfRingMul3 = 0;
-  const size_t wfFixed = (size_t)ctx->scene.numNodes * 32 + 64 * sizeof(int32_t);
+  // Hybrid form: the tree's top in LDS, the rest read from global memory (scene.nodesWf, built at upload when the tree does
+  // not fit or the tunable wf_resident_max asks for it).
+  const bool hybrid = p->traversal == SRT_TRAVERSE_FAITHFUL && ctx->scene.nodesWf != nullptr && ctx->tun.wavefront > 0 && !p->countStats &&
+                      ctx->scene.primClass != nullptr;
+  const size_t wfFixed = (size_t)(hybrid ? ctx->scene.wfResident : ctx->scene.numNodes) * 32 + 64 * sizeof(int32_t);
+  const size_t wfPerContext = hybrid ? 20 : 18;  // six ring slots of 16 bits, t, the primitive (16 bits; 32 in the hybrid form)
   {
     // ring counters are 32-bit and a 3 * 2^j ring cannot take their wrap-around: such rings only while a workgroup's
     // enqueues stay far below 2^32 (about three per sample)
     const double enqueuesPerGroup = 4.0 * (double)a.numLocalTiles * SRT_TILE_PIXELS * (double)p->spp / std::max(1, ctx->prop.multiProcessorCount);
     static const struct { int cap, shift, mul3; } kRings[] = {{4096, 12, 0}, {3072, 10, 1}, {2048, 11, 0}, {1536, 9, 1}, {1024, 10, 0}};
     for (const auto& r : kRings) {
-      if (r.cap > std::max(1024, ctx->tun.wfPool) || wfFixed + (size_t)18 * r.cap > 160 * 1024) continue;
+      if (r.cap > std::max(1024, ctx->tun.wfPool) || wfFixed + wfPerContext * r.cap > 160 * 1024) continue;
       if (r.mul3 && enqueuesPerGroup > 2.0e9) continue;
       wfRingCap = r.cap;
       wfRingShift = r.shift;
@@ -1286,13 +1410,14 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     }
     wfPoolSize = wfRingCap;
   }
-  const size_t wfLds = wfFixed + (size_t)18 * wfRingCap;
-  const bool wavefront = ldsTree && ctx->tun.wavefront > 0 && ctx->scene.numNodes >= ctx->tun.wavefront && !p->countStats && wfRingCap > 0 &&
-                         ctx->scene.primClass != nullptr;
+  const size_t wfLds = wfFixed + wfPerContext * wfRingCap;
+  const bool wavefront = wfRingCap > 0 && (hybrid || (ldsTree && ctx->tun.wavefront > 0 && ctx->scene.numNodes >= ctx->tun.wavefront && !p->countStats &&
+                                                      ctx->scene.primClass != nullptr));
+  if (!(wavefront && hybrid)) a.scene.nodesWf = nullptr;  // srt_launch_render_wf picks the form by this pointer
   int perCU = 0;
   if (wavefront || srt_render_occupancy(p->traversal, p->countStats, ldsTreeMode, lds, &perCU) != 0 || perCU < 1) perCU = 1;
   // persistent waves: enough workgroups to fill every CU, never more than there is work (4 or 16 waves each)
-  const int wgWaves = ldsTree ? 16 : 4;
+  const int wgWaves = ldsTree || wavefront ? 16 : 4;
   int grid = std::min(ctx->prop.multiProcessorCount * perCU, (a.numWork + SRT_TILE_PIXELS * wgWaves - 1) / (SRT_TILE_PIXELS * wgWaves));
   if (grid < 1) grid = 1;
   auto ensure = [&](DeviceBuffer& b, size_t need) -> int {
@@ -1317,6 +1442,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfRingShift = wfRingShift;
     a.wfRingMul3 = wfRingMul3;
     a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
+    a.wfFarRounds = ctx->tun.wfFarRounds > 0 ? std::min(64, ctx->tun.wfFarRounds) : (5 * (int64_t)ctx->scene.wfResident >= ctx->scene.numNodes ? 2 : 1);
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
   } else if (ldsTreeMode == 1 || attGlobal256) {
@@ -1326,9 +1452,9 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
   HIP_OK(ctx, hipMemsetAsync(ctx->dQueue, 0, sizeof(int32_t) * 16 * a.numQueues, stream));
   if (a.stats) HIP_OK(ctx, hipMemsetAsync(ctx->dStats, 0, 96 * sizeof(unsigned long long), stream));
   HIP_OK(ctx, hipEventRecord(ctx->evStart, stream));
-  ctx->lastLaunch[0] = wavefront ? 3 : ldsTreeMode;
+  ctx->lastLaunch[0] = wavefront ? (hybrid ? 4 : 3) : ldsTreeMode;
   ctx->lastLaunch[1] = grid;
-  ctx->lastLaunch[2] = ldsTree ? 1024 : 256;
+  ctx->lastLaunch[2] = ldsTree || wavefront ? 1024 : 256;
   ctx->lastLaunch[3] = (int32_t)(wavefront ? wfLds : lds);
   int rc = wavefront ? srt_launch_render_wf(&a, ctx->tun.wfProfile > 0, grid, wfLds, stream) : srt_launch_render(&a, p->traversal, p->countStats, ldsTreeMode, grid, lds, stream);
   if (rc) return fail(ctx, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1535,12 +1661,11 @@ int srtGetLaunchInfo(SrtContext* ctx, int32_t* out4) {
   memcpy(out4, ctx->lastLaunch, sizeof ctx->lastLaunch);
   return 0;
 }
-int srtGetWfProfile(SrtContext* ctx, uint64_t* out40) {
-  uint64_t* const out29 = out40;
-  if (!ctx || !out29) return 1;
+int srtGetWfProfile(SrtContext* ctx, uint64_t* out46) {
+  if (!ctx || !out46) return 1;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   HIP_OK(ctx, hipDeviceSynchronize());
-  HIP_OK(ctx, hipMemcpy(out29, ctx->dStats + 32, 40 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_OK(ctx, hipMemcpy(out46, ctx->dStats + 32, 46 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -80,6 +80,16 @@ struct DevScene {
   // map, 2 anything else.  A hit goes to its class's ring, so a hit step runs one class's code.
   const uint8_t* primClass;
   int32_t numPrimClass;
+  // path-pool kernel, hybrid form (a tree that does not fit into LDS): threaded records with 32-bit references --
+  // (bmin.xyz, reference taken on a box hit) (bmax.xyz, successor << 2 | what follows a leaf's first object: 0 nothing,
+  // 1 the next primitive of the same array, 2 primSecond[~first]) -- renumbered so that the wfResident nodes kept in LDS
+  // come first (srt_api.cpp: the boxes of largest surface, closed upward), the world list's roots in that numbering, and
+  // the second object of the leaves whose objects are not neighbours in one array (indexed like primClass).  "Done" is
+  // -2^29 here.  Null when the tree fits (or is not a host-built tree of two-node / two-primitive nodes).
+  const float4* nodesWf;
+  const int32_t* worldWf;
+  const int32_t* primSecond;
+  int32_t wfResident;
   const int32_t* triPrimId;  // device index -> index into the scene's prims[] list
   const int32_t* sphPrimId;
   const int32_t* world;  // refs, world-list order
@@ -151,6 +161,7 @@ struct RenderArgs {
   float* wfAttHi;
   int32_t wfPoolSize, wfRingCap, wfSwapMin, wfSwapBig;
   int32_t wfRingShift, wfRingMul3;  // wfRingCap = (wfRingMul3 ? 3 : 1) << wfRingShift
+  int32_t wfFarRounds;  // hybrid form: node visits per round (the last one serves the lanes outside LDS as well)
   int32_t* wfError;
 };
 

@@ -66,38 +66,52 @@ __device__ __forceinline__ uint32_t bufLoad1(Rsrc r, int off) { return __builtin
 
 // SINGLE: the world list is one tree (as in srt_render_kernel).  PROFILE (tunable wf_profile, tools/wf_profile.py): per
 // step kind, the clocks the waves spent in it, its executions and the lanes they served -> RenderArgs::stats[32 + ...]
-// (kinds: 0 node visit, 1 primitive test, 2 swap, 3-5 hit step per class, 6 restart, 7 idle, 8 lost claim, 9 item pull).
-#define WF_PROF_KINDS 10
-template <bool SINGLE, bool PROFILE>
+// (kinds: 0 node visit, 1 primitive test, 2 swap, 3-5 hit step per class, 6 restart, 7 idle, 8 lost claim, 9 item pull,
+// 10 visit of a node outside LDS -- hybrid form: wait for the records + visit; its clocks are part of kind 0's as well).
+#define WF_PROF_KINDS 12
+// HYBRID: the tree does not fit into LDS.  Its top -- the first `resident` records of DevScene::nodesWf, the boxes a ray is
+// most likely to meet -- is kept there, the other records are read from global memory where the walk reaches them; a
+// node round asks for the global lanes' records first and visits LDS nodes with the other lanes while they are on the way.
+template <bool SINGLE, bool PROFILE, bool HYBRID>
 __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const RenderArgs a) {
 
-  constexpr int32_t DONE = (int32_t)0xFFFF8000;       // the 16-bit "no reference", sign-extended
-  constexpr int32_t DONE_PAIR = (int32_t)0x80008000;  // both halves of a thread link
+  // whole tree in LDS: 16-bit references, DONE = the 16-bit "no reference" sign-extended, a link = two of them.
+  // HYBRID: 32-bit references, DONE = -2^29, a link = successor << 2 | what follows a leaf's first object (srt_device.h)
+  constexpr int32_t DONE = HYBRID ? -(1 << 29) : (int32_t)0xFFFF8000;
+  constexpr int32_t DONE_PAIR = HYBRID ? (int32_t)0x80000000 : (int32_t)0x80008000;  // "nothing follows, then done"
+  constexpr int LINK_SHIFT = HYBRID ? 2 : 16;
+  typedef typename std::conditional<HYBRID, int32_t, uint16_t>::type PrimSlot;
   extern __shared__ int32_t lds[];
   const DevScene& sc = a.scene;
   char* const ldsTree = reinterpret_cast<char*>(lds);
-  const int treeBytes = sc.numNodes * 32;
+  const int resident = HYBRID ? sc.wfResident : sc.numNodes;  // nodes [0, resident) are in LDS
+  const int treeBytes = resident * 32;
   int32_t* const ctl = reinterpret_cast<int32_t*>(ldsTree + treeBytes);
   const int RCAP = a.wfRingCap, POOL = a.wfPoolSize;
   uint16_t* const ringSlots = reinterpret_cast<uint16_t*>(ctl + WF_CTL_WORDS);
   float* const hitT = reinterpret_cast<float*>(ringSlots + WF_RINGS * RCAP);
-  uint16_t* const hitPrim = reinterpret_cast<uint16_t*>(hitT + POOL);
+  PrimSlot* const hitPrim = reinterpret_cast<PrimSlot*>(hitT + POOL);
   const int lane = threadIdx.x & 63;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
   const uint64_t seedMixed = mix64(a.seed);
   const V3 background = ld3(a.background);
-  const Rsrc rsNodes = makeRsrc(sc.nodes, sc.numNodes * 32);
+  const Rsrc rsNodes = makeRsrc(HYBRID ? sc.nodesWf : sc.nodes, sc.numNodes * 32);
   const Rsrc rsTris = makeRsrc(sc.triTest, sc.numTris * 48);
   const Rsrc rsSpheres = makeRsrc(sc.spheres, sc.numSpheres * 48);
   const Rsrc rsTexels = makeRsrc(sc.texels, sc.texelBytes);
   const Rsrc rsClass = makeRsrc(sc.primClass, sc.numPrimClass);
+  const Rsrc rsSecond = makeRsrc(sc.primSecond, HYBRID ? sc.numPrimClass * 4 : 0);
   // this workgroup's contexts: id << 7 is a context's byte offset; attenuation levels of bounces >= 4 live in
   // [level - 4][channel][id] in a second array
   const Rsrc rsPool = makeRsrc(a.wfPool + (size_t)blockIdx.x * POOL * WF_CTX_BYTES, POOL * WF_CTX_BYTES);
   const int hiLevels = a.maxBounce > 4 ? a.maxBounce - 4 : 0;
   const Rsrc rsAttHi = makeRsrc(a.wfAttHi + (size_t)blockIdx.x * 3 * hiLevels * POOL, 3 * hiLevels * POOL * 4);
   const bool singleRoot = SINGLE || sc.numWorld == 1;
-  auto localRef = [&](int r) { return r >= 0 ? r >> 5 : r; };
+  auto worldRef = [&](int k) {
+    if (HYBRID) return sc.worldWf[k];
+    const int r = sc.world[k];
+    return r >= 0 ? r >> 5 : r;
+  };
   // place of counter value c in a ring: c mod RCAP, RCAP = 2^j or 3 * 2^j (the pool size rounded up to such a number)
   const int ringShift = a.wfRingShift;
   const bool ringMul3 = a.wfRingMul3 != 0;
@@ -111,13 +125,15 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   // ---- set-up: the threaded tree into LDS (as srt_render_kernel LDSTREE), empty rings, every context waits for an item
   {
     float4* dst = reinterpret_cast<float4*>(ldsTree);
-    for (int i = threadIdx.x; i < sc.numNodes * 2; i += WF_BLOCK) {
+    for (int i = threadIdx.x; i < resident * 2; i += WF_BLOCK) {
       float4 v = bufLoad4(rsNodes, 16 * i);
-      const int r = __float_as_int(v.w);
-      if (i & 1)
-        v.w = __int_as_float(sc.nodeThread[i >> 1]);
-      else if (r >= 0)
-        v.w = __int_as_float(r >> 5);
+      if (!HYBRID) {  // nodesWf holds the threaded records already
+        const int r = __float_as_int(v.w);
+        if (i & 1)
+          v.w = __int_as_float(sc.nodeThread[i >> 1]);
+        else if (r >= 0)
+          v.w = __int_as_float(r >> 5);
+      }
       dst[i] = v;
     }
     for (int i = threadIdx.x; i < WF_CTL_WORDS; i += WF_BLOCK) ctl[i] = 0;
@@ -231,10 +247,19 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
   auto atNode = [&]() { return cur >= 0; };
   auto atPrim = [&]() { return (uint32_t)cur > (uint32_t)DONE; };
   auto popNext = [&]() {
-    int next = (int32_t)(int16_t)link;
-    link >>= 16;
+    int next;
+    if (HYBRID) {
+      const int follows = link & 3;
+      next = link >> 2;
+      if (follows == 1) next = cur - 2;                                                                   // the next primitive of the same array
+      if (follows == 2) next = (int)__builtin_amdgcn_raw_buffer_load_b32(rsSecond, (~cur) << 2, 0, 0);  // any other pair (rare)
+      link &= ~3;
+    } else {
+      next = (int32_t)(int16_t)link;
+      link >>= 16;
+    }
     if (!SINGLE && !singleRoot && next == DONE && ++w < sc.numWorld) {
-      next = localRef(sc.world[w]);
+      next = worldRef(w);
       link = DONE_PAIR;
     }
     cur = next;
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     hitRef = DONE;
     link = DONE_PAIR;
     w = 0;
-    cur = localRef(sc.world[0]);
+    cur = worldRef(0);
   };
   // the next camera ray of a context (main.cpp:204-216): A, B, C of its line
   auto cameraRayInto = [&](int at, uint32_t pxy, int s) {
@@ -334,35 +359,67 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105, over the threaded tree in LDS
       const int keep = (nNodes * a.keepEighths) >> 3;
       int budget = a.nodeBurst;
-      auto nodeVisit = [&]() {
+      auto visit = [&](const float4 n0, const float4 n1) {  // aabb::hit (certified slab test, IEEE when undecided), then on
+        bool undecided;
+        bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
+        if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
+          const unsigned long long mu = __ballot(undecided);
+          pLanes[8] += __popcll(mu);
+          pLanes[7] += mu != 0 ? 1 : 0;
+        }
+        if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
+        link = __float_as_int(n1.w);
+        cur = hitBox ? __float_as_int(n0.w) : (link >> LINK_SHIFT);
+        if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
+          cur = worldRef(w);
+          link = DONE_PAIR;
+        }
+      };
+      auto nodeVisit = [&](bool mine) {
+        const bool here = HYBRID ? mine && (uint32_t)cur < (uint32_t)resident : cur >= 0;
         if (PROFILE) {
           pRuns[0]++;
-          pLanes[0] += __popcll(__ballot(atNode()));
+          pLanes[0] += __popcll(__ballot(here));
         }
-        if (atNode()) {
+        if (here) {
           const char* rec = ldsTree + (cur << 5);
-          const float4 n0 = *reinterpret_cast<const float4*>(rec);
-          const float4 n1 = *reinterpret_cast<const float4*>(rec + 16);
-          bool undecided;
-          bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
-          if (PROFILE) {  // how often the certificate cannot decide: lanes (-> lanes[8]) and wave visits that run the IEEE test (-> lanes[7])
-            const unsigned long long mu = __ballot(undecided);
-            pLanes[8] += __popcll(mu);
-            pLanes[7] += mu != 0 ? 1 : 0;
-          }
-          if (undecided) hitBox = boxHit(n0, n1, ray, a.tMin, closest);
-          link = __float_as_int(n1.w);
-          cur = hitBox ? __float_as_int(n0.w) : (link >> 16);
-          if (!SINGLE && !singleRoot && cur == DONE && ++w < sc.numWorld) {
-            cur = localRef(sc.world[w]);
-            link = DONE_PAIR;
-          }
+          visit(*reinterpret_cast<const float4*>(rec), *reinterpret_cast<const float4*>(rec + 16));
         }
       };
       do {
+        if (HYBRID) {
+          // the lanes at a node outside LDS ask for its record; the others visit LDS nodes meanwhile (wfFarRounds - 1 times,
+          // or until none of them is at one) and then fetch one more record from LDS, so that the last visit of the round
+          // serves both groups in one execution
+          const bool far = cur >= resident;
+          float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
+          if (far) {
+            g0 = bufLoad4(rsNodes, cur << 5);
+            g1 = bufLoad4(rsNodes, (cur << 5) + 16);
+          }
+          for (int u = 1; u < a.wfFarRounds; ++u) {
+            if (__ballot(!far && (uint32_t)cur < (uint32_t)resident) == 0) break;
+            nodeVisit(!far);
+          }
+          const bool near = !far && (uint32_t)cur < (uint32_t)resident;
+          if (near) {
+            const char* rec = ldsTree + (cur << 5);
+            g0 = *reinterpret_cast<const float4*>(rec);
+            g1 = *reinterpret_cast<const float4*>(rec + 16);
+          }
+          const unsigned long long f0 = PROFILE ? clock64() : 0;
+          if (far || near) visit(g0, g1);
+          if (PROFILE) {
+            pRuns[10]++;
+            pLanes[10] += __popcll(__ballot(far));
+            pLanes[11] += __popcll(__ballot(near));
+            pCyc[10] += clock64() - f0;
+          }
+        } else {
 #pragma unroll
-        for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit();
-        budget -= SRT_NODE_UNROLL;
+          for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit(true);
+        }
+        budget -= HYBRID ? a.wfFarRounds : SRT_NODE_UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
       if (PROFILE) {
         const unsigned long long now = clock64();
@@ -393,7 +450,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         // what the hit step needs beyond the ray: t and the primitive (LDS).  A miss leaves nothing: the context already
         // says "in flight, nothing hit".
         __hip_atomic_store(&hitT[path], closest, __ATOMIC_RELAXED, WF_WG);
-        __hip_atomic_store(&hitPrim[path], (uint16_t)hitRef, __ATOMIC_RELAXED, WF_WG);
+        __hip_atomic_store(&hitPrim[path], (PrimSlot)hitRef, __ATOMIC_RELAXED, WF_WG);
       }
       asm volatile("" ::: "memory");  // the ring slot is written after them (one wave's LDS operations execute in order)
       enqueue(!fin ? -1 : (hit ? WF_RING_HIT + cls : WF_RING_RESTART), path);
@@ -435,7 +492,8 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           const float4 A = bufLoad4(rsPool, at), B = bufLoad4(rsPool, at + 16);
           const u32x4 C = __builtin_amdgcn_raw_buffer_load_b128(rsPool, at + 32, 0, 0);
           const float tHit = __hip_atomic_load(&hitT[id], __ATOMIC_RELAXED, WF_WG);
-          const int pr = ~(int)(int16_t)__hip_atomic_load(&hitPrim[id], __ATOMIC_RELAXED, WF_WG);
+          const int pr = HYBRID ? ~(int)__hip_atomic_load(&hitPrim[id], __ATOMIC_RELAXED, WF_WG)
+                                : ~(int)(int16_t)__hip_atomic_load(&hitPrim[id], __ATOMIC_RELAXED, WF_WG);
           Ray rIn;
           rIn.o = mk(A.x, A.y, A.z);
           rIn.d = mk(B.x, B.y, B.z);
@@ -763,8 +821,9 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
 extern "C" {
 int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream) {
   typedef void (*Kernel)(const RenderArgs);
-  const Kernel k = profile ? srt_render_wf_kernel<false, true>
-                           : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false> : srt_render_wf_kernel<false, false>);
+  const Kernel k = a->scene.nodesWf ? (profile ? srt_render_wf_kernel<false, true, true> : srt_render_wf_kernel<false, false, true>)
+                   : profile       ? srt_render_wf_kernel<false, true, false>
+                                   : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false, false> : srt_render_wf_kernel<false, false, false>);
   if (ldsBytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return (int)e;

@@ -278,22 +278,24 @@ class Context:
 
     def wf_profile(self):
         """Step profile of the last path-pool launch with tunable wf_profile = 1 (include/srt_hip_test.h)."""
-        out = np.zeros(40, np.uint64)
+        out = np.zeros(46, np.uint64)
         self._check(lib.srtGetWfProfile(self.h, out.ctypes.data))
-        kinds = ["node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "idle", "lost_claim", "new_item"]
-        prof = {k: {"clocks": int(out[i]), "runs": int(out[10 + i]), "lanes": int(out[20 + i])} for i, k in enumerate(kinds)}
-        prof["sched_clocks"], prof["total_clocks"] = int(out[30]), int(out[31])
-        n = max(1, int(out[32]))
-        prof["decisions"] = int(out[32])
-        prof["mean_seen"] = {k: float(out[33 + i]) / n for i, k in enumerate(["at_node", "at_prim", "finished", "idle", "ready_fill", "fullest_ring", "restart_fill"])}
+        kinds = ["node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "idle", "lost_claim", "new_item", "far_node", "unused"]
+        K = len(kinds)
+        prof = {k: {"clocks": int(out[i]), "runs": int(out[K + i]), "lanes": int(out[2 * K + i])} for i, k in enumerate(kinds)}
+        prof["sched_clocks"], prof["total_clocks"] = int(out[3 * K]), int(out[3 * K + 1])
+        n = max(1, int(out[3 * K + 2]))
+        prof["decisions"] = int(out[3 * K + 2])
+        prof["mean_seen"] = {k: float(out[3 * K + 3 + i]) / n for i, k in enumerate(["at_node", "at_prim", "finished", "idle", "ready_fill", "fullest_ring", "restart_fill"])}
         return prof
 
     def launch_info(self):
         """The most recent render launch (include/srt_hip_test.h).  lds_tree_mode: 0 node records through the L1,
-        1 / 2 LDS-resident tree with the attenuation stacks in global memory / LDS, 3 the path-pool kernel."""
+        1 / 2 LDS-resident tree with the attenuation stacks in global memory / LDS, 3 the path-pool kernel, 4 its hybrid form
+        (the tree's top in LDS, the rest read from global memory)."""
         out = np.zeros(4, np.int32)
         self._check(lib.srtGetLaunchInfo(self.h, out.ctypes.data))
-        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "wavefront": int(out[0]) == 3, "workgroups": int(out[1]),
+        return {"lds_tree": bool(out[0]), "lds_tree_mode": int(out[0]), "wavefront": int(out[0]) in (3, 4), "hybrid": int(out[0]) == 4, "workgroups": int(out[1]),
                 "threads": int(out[2]), "lds_bytes": int(out[3])}
 
     def last_kernel_ms(self):

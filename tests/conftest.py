@@ -54,16 +54,19 @@ def camera(dev, abi):
     return dev.make_camera(abi.default_camera_params())
 
 
-@pytest.fixture(params=["wavefront", "lds_tree", "l1_nodes"])
+@pytest.fixture(params=["wavefront", "hybrid", "lds_tree", "l1_nodes"])
 def node_path(request, ctx):
-    """The three forms of the FAITHFUL render kernel: the path-pool kernel (srt_wavefront.hip: lanes traverse the
+    """The forms of the FAITHFUL render kernel: the path-pool kernel (srt_wavefront.hip: lanes traverse the
     LDS-resident threaded tree, full waves shade contexts taken from per-class rings; the default for scenes whose node
-    array fits a CU's LDS), the step-scheduler kernel over the same LDS-resident tree (tunable wavefront = 0), and the
-    256-thread step-scheduler kernel that reads the node records through the vector L1 (lds_tree = 0; what larger
-    scenes get).  A counting launch (count_stats) of the first runs the second: the counters belong to the scene."""
-    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront")}
+    array fits a CU's LDS), its hybrid form (only the tree's top in LDS, the other records read from global memory: what
+    trees too large for LDS get; here forced onto every tree of more than 24 nodes with the tunable wf_resident_max), the
+    step-scheduler kernel over the LDS-resident tree (tunable wavefront = 0), and the 256-thread step-scheduler kernel
+    that reads the node records through the vector L1 (lds_tree = 0).  A counting launch (count_stats) of the first two
+    runs the third: the counters belong to the scene."""
+    saved = {k: ctx.get_tunable(k) for k in ("lds_tree", "wavefront", "wf_resident_max")}
     ctx.set_tunable("lds_tree", 0 if request.param == "l1_nodes" else 1)  # 1: every tree that fits, however small
-    ctx.set_tunable("wavefront", 1 if request.param == "wavefront" else 0)
+    ctx.set_tunable("wavefront", 1 if request.param in ("wavefront", "hybrid") else 0)
+    ctx.set_tunable("wf_resident_max", 24 if request.param == "hybrid" else 0)  # read at upload: the tests upload after this
     yield request.param
     for k, v in saved.items():
         ctx.set_tunable(k, v)
@@ -73,7 +76,7 @@ def render_counted(ctx, p, node_path):
     """ctx.render_image(p) for a test that also reads ctx.stats(): the image comes from the kernel under test, the
     counters from the counting variant.  For the path-pool kernel these are two launches (its counting variant is the
     step-scheduler kernel over the same tree), and the image is checked to come from the path-pool kernel itself."""
-    if node_path != "wavefront" or not p.countStats:
+    if node_path not in ("wavefront", "hybrid") or not p.countStats:
         return ctx.render_image(p)
     p.countStats = 0
     acc, rgba = ctx.render_image(p)

@@ -225,7 +225,7 @@ def test_render_720p_headline_frame_vs_oracle(ctx, oracle, abi, scenes, camera, 
         assert_accum_close(acc, want_acc, min_bitexact=0.999 if chunks == 1 else 0.0)
         assert_rgba_close(rgba, want_rgba)
     info = ctx.launch_info()
-    assert info["lds_tree_mode"] == {"wavefront": 3, "lds_tree": 1, "l1_nodes": 0}[node_path], info
+    assert info["lds_tree_mode"] == {"wavefront": 3, "hybrid": 4, "lds_tree": 1, "l1_nodes": 0}[node_path], info
 
 
 FULL_SIZE_CONFIGS = {  # BASELINE.json configs[1..4] at their own size; two adjacent pixel rows each
@@ -368,7 +368,7 @@ def test_render_kernel_traversal_per_ray_vs_oracle(ctx, oracle, abi, scenes, cam
     `depth` of the first sample and the hit, t and counters its scheduler-driven traversal (one-FMA slab
     certificate, LDS stack with sentinel, node bursts) produced; the oracle's world.hit() (bvh.h:97-105
     recursion, IEEE divisions) on the same rays must agree bit for bit, counters included."""
-    if node_path == "wavefront":
+    if node_path in ("wavefront", "hybrid"):
         pytest.skip("a counting launch of the path-pool kernel IS the step-scheduler kernel over the same threaded tree (lds_tree)")
     sb = scenes[name]
     ctx.upload_scene(sb)

@@ -650,10 +650,22 @@ def test_lds_resident_tree_is_used_and_changes_nothing(ctx, dev, abi, srt, camer
                         ctx.set_tunable(k, v)
             for path in ("wavefront", "lds_tree"):
                 assert np.array_equal(images[path].view(np.uint32), images["l1_nodes"].view(np.uint32)), (name, chunks, path)
-    # a tree that does not fit: 40 000 triangles -> ~40 000 nodes, 1.3 MB
-    ctx.upload_scene(srt.scenes.scene_soup(40000, seed=5, extent=6.0, size=0.1))
-    ctx.set_camera(camera)
-    local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
-    ctx.render_tiles(abi.default_render_params(W, H, 2, 4, seed=3), local.data_ptr(), None)
-    torch.cuda.synchronize()
-    assert not ctx.launch_info()["lds_tree"]
+    # a tree that does not fit: 40 000 triangles -> ~40 000 nodes, 1.3 MB.  The path-pool kernel's hybrid form keeps its top
+    # in LDS and reads the rest from global memory (32-bit references); with wf_hybrid = 0 (read at upload) the 256-thread
+    # kernel renders it.  Same bits.
+    big = {}
+    for hybrid in (1, 0):
+        ctx.set_tunable("wf_hybrid", hybrid)
+        try:
+            ctx.upload_scene(srt.scenes.scene_soup(40000, seed=5, extent=6.0, size=0.1))
+        finally:
+            ctx.set_tunable("wf_hybrid", 1)
+        ctx.set_camera(camera)
+        local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
+        ctx.render_tiles(abi.default_render_params(W, H, 2, 4, seed=3), local.data_ptr(), None)
+        torch.cuda.synchronize()
+        ctx.last_kernel_ms()
+        info = ctx.launch_info()
+        assert info["lds_tree_mode"] == (4 if hybrid else 0) and info["threads"] == (1024 if hybrid else 256), info
+        big[hybrid] = local.cpu().numpy()
+    assert np.array_equal(big[1].view(np.uint32), big[0].view(np.uint32))

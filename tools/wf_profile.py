@@ -12,7 +12,7 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1280, 720)
 mb = 8 if scene in ("spheres", "sphere_field") else 4
 ctx = dev.Context(0)
-ctx.upload_scene(srt.scenes.SCENES[scene]())
+ctx.upload_scene(srt.scenes.scene_soup(int(scene[5:])) if scene.startswith("soup:") else srt.scenes.SCENES[scene]())
 ctx.set_camera(dev.make_camera(abi.default_camera_params()))
 local = torch.zeros((dev.num_local_tiles(W, H, 1), 64, 4), dtype=torch.float32, device="cuda")
 p = abi.default_render_params(W, H, spp, mb, seed=1, spp_chunks=0)
@@ -27,10 +27,13 @@ for prof in (0, 1):
 pr = ctx.wf_profile()
 tot = pr["total_clocks"]
 samples = W * H * spp
-for k in ("node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "new_item", "idle", "lost_claim"):
+for k in ("node", "far_node", "prim", "swap", "hit0", "hit1", "hit2", "restart", "new_item", "idle", "lost_claim"):
     v = pr[k]
     print("%-10s %5.1f%% of wave time, %11d executions, mean fill %5.1f lanes, %8.1f clocks/execution, %.3f executions/sample" % (
         k, 100.0 * v["clocks"] / tot, v["runs"], v["lanes"] / max(1, v["runs"]), v["clocks"] / max(1, v["runs"]), v["runs"] / samples))
+if pr["far_node"]["runs"]:
+    print("hybrid form: the closing visit of a round served %.1f lanes outside LDS and %.1f lanes in LDS on average" % (
+        pr["far_node"]["lanes"] / pr["far_node"]["runs"], pr["unused"]["lanes"] / pr["far_node"]["runs"]))
 print("slab certificate: %.4f%% of lane visits undecided, %.2f%% of wave visits ran the IEEE test" % (
     100.0 * pr["lost_claim"]["lanes"] / max(1, pr["node"]["lanes"]), 100.0 * pr["idle"]["lanes"] / max(1, pr["node"]["runs"])))
 print("%-10s %5.1f%% of wave time, %d decisions (%.2f per sample)" % ("scheduling", 100.0 * pr["sched_clocks"] / tot, pr["decisions"], pr["decisions"] / samples))

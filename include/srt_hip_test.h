@@ -49,6 +49,19 @@ int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10);
  * READY fill, fill of the fullest served ring, RESTART fill. */
 int srtGetWfProfile(SrtContext* ctx, uint64_t* out46);
 
+/* Host-only (no device): the thread links srtUploadScene builds for the stackless walks (csrc/srt_thread.h) from a
+ * flattened node array -- nodes8 = numNodes x 8 floats, (bmin.xyz, left) (bmax.xyz, right), node references = index * 32,
+ * primitives = ~(index << 1 | sphere) -- and the world list's references.
+ * srtTestThreadLinks16: one word per node (DevScene::nodeThread) -> outLinks[numNodes]; returns 1, or 0 when the forest has
+ * no 16-bit threaded form.
+ * srtTestHybridRecords: the path-pool kernel's hybrid records (DevScene::nodesWf / worldWf / primSecond) with at most `cap`
+ * resident nodes -> outNodes8[numNodes x 8], outWorld[numWorld], outSecond[2 * max(numTriangles, numSpheres) + 2]; returns
+ * the number of resident nodes, or 0 when the forest has no threaded form.  Both return -1 on a null argument. */
+int srtTestThreadLinks16(const float* nodes8, int32_t numNodes, const int32_t* world, int32_t numWorld, int32_t numTriangles, int32_t numSpheres,
+                         int32_t* outLinks);
+int srtTestHybridRecords(const float* nodes8, int32_t numNodes, const int32_t* world, int32_t numWorld, int32_t numTriangles, int32_t numSpheres,
+                         int32_t cap, float* outNodes8, int32_t* outWorld, int32_t* outSecond);
+
 /* The most recent render-kernel launch: out4 = { 0 node records through the L1, 1 the step-scheduler kernel over the
  * LDS-resident threaded tree (FAITHFUL, node array small enough for a CU's LDS; tunable "lds_tree" = 0 switches it
  * off), 2 the same with the attenuation stacks in LDS as well, 3 the path-pool kernel over the same tree (tunable

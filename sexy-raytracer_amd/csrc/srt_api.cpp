@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "srt_device.h"
+#include "srt_thread.h"
 
 extern "C" {
 int srt_launch_render(const RenderArgs* a, int traversal, int count, int ldsTree, int grid, size_t ldsBytes, hipStream_t stream);
@@ -861,154 +862,23 @@ static int srtUploadSceneImpl(SrtContext* ctx, const SrtSceneDesc* d) {
       triDevIndex.swap(order);  // devRef of the device-built trees below
     }
   }
-  // ---- thread links of the LDS-resident-tree kernel (DevScene::nodeThread): bvh.h:102-103 visits left, then right,
-  // always, so "where to go when this subtree is done" is a property of the tree: the right sibling's subtree for a
-  // left child, the parent's successor for a right child, "done" for a root.  16 bits per reference (node index,
-  // ~primitive, 0x8000 = done).  Only for scenes whose trees were all built on the host out of nodes with two node
-  // children or two primitive children (bvh.h:55-95 builds nothing else; a caller-built tree may).
+  // ---- thread links (srt_thread.h): the 16-bit form the LDS-resident-tree kernels walk (DevScene::nodeThread), and for a
+  // tree that does not fit into LDS the path-pool kernel's hybrid records (32-bit references, resident nodes first)
+  bool hostTrees = true;
+  for (const auto& dt : ctx->itemDeviceTree) hostTrees = hostTrees && dt.base < 0;
   std::vector<int32_t> nodeThread;
-  {
-    const size_t n = nodes.size() / 2;
-    auto refOf = [&](size_t slot) {
-      int32_t r;
-      memcpy(&r, &nodes[slot].w, 4);
-      return r;
-    };
-    bool ok = n > 0 && n < 32767 && 2 * (int64_t)d->numTriangles < 32766 && 2 * (int64_t)d->numSpheres + 1 < 32766;
-    for (const auto& dt : ctx->itemDeviceTree) ok = ok && dt.base < 0;
-    for (size_t i = 0; ok && i < n; ++i) ok = (refOf(2 * i) >= 0) == (refOf(2 * i + 1) >= 0);
-    if (ok) {
-      const int32_t kDone = 0x8000;
-      auto ref16 = [&](int32_t r) { return (uint32_t)(r >= 0 ? SRT_NODE_INDEX(r) : r) & 0xffffu; };  // r: device reference
-      nodeThread.assign(n, (int32_t)((uint32_t)kDone << 16 | (uint32_t)kDone));
-      std::vector<uint8_t> seen(n, 0);
-      std::vector<std::pair<int32_t, uint32_t>> todo;  // (node index, its successor as 16 bits)
-      for (int32_t wr : world)
-        if (wr >= 0) todo.emplace_back(SRT_NODE_INDEX(wr), (uint32_t)kDone);
-      while (ok && !todo.empty()) {
-        const auto [i, after] = todo.back();
-        todo.pop_back();
-        if (i < 0 || (size_t)i >= n || seen[i]) {  // a node reached twice is not a tree: leave it to the stack walk
-          ok = false;
-          break;
-        }
-        seen[i] = 1;
-        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
-        if (l >= 0) {
-          nodeThread[i] = (int32_t)(after << 16 | after);
-          todo.emplace_back(SRT_NODE_INDEX(r), after);          // the right subtree is followed by this node's successor
-          todo.emplace_back(SRT_NODE_INDEX(l), ref16(r));       // the left subtree by the right child
-        } else {
-          nodeThread[i] = (int32_t)(after << 16 | (r != l ? ref16(r) : after));  // first object -> second object (or on)
-        }
-      }
-    }
-    if (!ok) nodeThread.clear();
-  }
-  // ---- path-pool kernel, hybrid form (srt_wavefront.hip HYBRID): threaded records with 32-bit references, renumbered so
-  // that the RESIDENT nodes come first.  Resident = the wfResident boxes of largest surface area reachable from the roots
-  // (a child's box lies inside its parent's, so the set is closed upward: a walk leaves LDS once per excursion and comes
-  // back through a thread link).  Inside each group the order is the trees' pre-order.
-  // Record = (bmin.xyz, reference taken on a box hit) (bmax.xyz, link), node references = new indices, link = successor
-  // << 2 | what follows a leaf's FIRST object: 0 nothing (a single-object leaf), 1 the next primitive of the same array
-  // (reference - 2: the leaves' triangles are neighbours in tree order, above), 2 primSecond[~first] (any other pair).
-  // Successor = where the walk goes when this node's subtree is done: a node index or kDoneW.  Same trees as nodeThread:
-  // host-built, every node's children two nodes or two primitives -- but no 15-bit limit.
   std::vector<float4> nodesWf;
   std::vector<int32_t> worldWf, primSecond;
   int32_t wfResident = 0;
-  if (ctx->tun.wfHybrid > 0 && !nodes.empty()) {
-    const size_t n = nodes.size() / 2;
-    const size_t fits = (160 * 1024 - 64 * sizeof(int32_t) - 20 * 2048) / 32;       // beside a pool of 2048 contexts
-    const size_t fitsWhole = (160 * 1024 - 64 * sizeof(int32_t) - 18 * 1024) / 32;  // the whole-tree form's smallest pool
-    const size_t cap = ctx->tun.wfResidentMax > 0 ? std::min<size_t>(fits, (size_t)ctx->tun.wfResidentMax) : fits;
-    const int32_t kDoneW = -(1 << 29);
-    auto refOf = [&](size_t slot) {
-      int32_t r;
-      memcpy(&r, &nodes[slot].w, 4);
-      return r;
-    };
-    bool ok = n > (ctx->tun.wfResidentMax > 0 ? cap : fitsWhole) && n < ((size_t)1 << 28) &&
-              (int64_t)d->numTriangles < (1 << 27) && (int64_t)d->numSpheres < (1 << 27);
-    for (const auto& dt : ctx->itemDeviceTree) ok = ok && dt.base < 0;
-    for (size_t i = 0; ok && i < n; ++i) ok = (refOf(2 * i) >= 0) == (refOf(2 * i + 1) >= 0);
-    // successor of every node (original indices, -1 = done), pre-order of the world's trees
-    std::vector<int32_t> succ, preorder;
-    if (ok) {
-      succ.assign(n, -2);
-      preorder.reserve(n);
-      std::vector<std::pair<int32_t, int32_t>> todo;
-      for (auto it = world.rbegin(); it != world.rend(); ++it)
-        if (*it >= 0) todo.emplace_back(SRT_NODE_INDEX(*it), -1);
-      while (ok && !todo.empty()) {
-        const auto [i, after] = todo.back();
-        todo.pop_back();
-        if (i < 0 || (size_t)i >= n || succ[i] != -2) {  // a node reached twice is not a tree: leave it to the stack walk
-          ok = false;
-          break;
-        }
-        succ[i] = after;
-        preorder.push_back(i);
-        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
-        if (l >= 0) {
-          todo.emplace_back(SRT_NODE_INDEX(r), after);             // the right subtree is followed by this node's successor
-          todo.emplace_back(SRT_NODE_INDEX(l), SRT_NODE_INDEX(r));  // the left subtree by the right child
-        }
-      }
-    }
-    if (ok && !preorder.empty()) {
-      auto area = [&](size_t i) {
-        const float4 &lo = nodes[2 * i], &hi = nodes[2 * i + 1];
-        const double x = (double)hi.x - lo.x, y = (double)hi.y - lo.y, z = (double)hi.z - lo.z;
-        const double s2 = x * y + y * z + z * x;
-        return s2 == s2 ? s2 : 1e300;  // a NaN box is visited like any other: keep it near the top
-      };
-      std::vector<uint8_t> resident(n, 0);
-      std::priority_queue<std::pair<double, int32_t>> open;
-      for (int32_t wr : world)
-        if (wr >= 0) open.emplace(area((size_t)SRT_NODE_INDEX(wr)), -SRT_NODE_INDEX(wr));  // ties: the lower index first
-      size_t k = 0;
-      while (k < cap && !open.empty()) {
-        const int32_t i = -open.top().second;
-        open.pop();
-        resident[i] = 1;
-        ++k;
-        const int32_t l = refOf(2 * (size_t)i), r = refOf(2 * (size_t)i + 1);
-        if (l >= 0) {
-          open.emplace(area((size_t)SRT_NODE_INDEX(l)), -SRT_NODE_INDEX(l));
-          open.emplace(area((size_t)SRT_NODE_INDEX(r)), -SRT_NODE_INDEX(r));
-        }
-      }
-      wfResident = (int32_t)k;
-      std::vector<int32_t> newIndex(n, -1);
-      int32_t nextRes = 0, nextGlob = wfResident;
-      for (int32_t i : preorder) newIndex[i] = resident[i] ? nextRes++ : nextGlob++;
-      for (size_t i = 0; i < n; ++i)
-        if (newIndex[i] < 0) newIndex[i] = nextGlob++;  // not part of any tree of the world list: never visited
-      primSecond.assign((size_t)2 * std::max(d->numTriangles, d->numSpheres) + 2, kDoneW);
-      nodesWf.resize(2 * n);
-      for (size_t i = 0; i < n; ++i) {
-        float4 lo = nodes[2 * i], hi = nodes[2 * i + 1];
-        const int32_t l = refOf(2 * i), r = refOf(2 * i + 1);
-        const int32_t after = succ[i] >= 0 ? newIndex[succ[i]] : kDoneW;  // (-2, an unreachable node: never read)
-        int32_t taken = l, flag = 0;
-        if (l >= 0) {
-          taken = newIndex[SRT_NODE_INDEX(l)];
-        } else if (r != l) {
-          if (r == l - 2 && ((~l) & 1) == ((~r) & 1)) {
-            flag = 1;
-          } else {
-            flag = 2;
-            primSecond[(size_t)~l] = r;
-          }
-        }
-        const int32_t link = (int32_t)((uint32_t)after << 2) | flag;
-        memcpy(&lo.w, &taken, 4);
-        memcpy(&hi.w, &link, 4);
-        nodesWf[2 * (size_t)newIndex[i]] = lo;
-        nodesWf[2 * (size_t)newIndex[i] + 1] = hi;
-      }
-      for (int32_t wr : world) worldWf.push_back(wr >= 0 ? newIndex[SRT_NODE_INDEX(wr)] : wr);
+  if (hostTrees && !nodes.empty()) {
+    srtThreadLinks16(nodes, world, d->numTriangles, d->numSpheres, nodeThread);
+    if (ctx->tun.wfHybrid > 0) {
+      const size_t n = nodes.size() / 2;
+      const size_t fits = (160 * 1024 - 64 * sizeof(int32_t) - 20 * 2048) / 32;       // beside a pool of 2048 contexts
+      const size_t fitsWhole = (160 * 1024 - 64 * sizeof(int32_t) - 18 * 1024) / 32;  // the whole-tree form's smallest pool
+      const size_t cap = ctx->tun.wfResidentMax > 0 ? std::min<size_t>(fits, (size_t)ctx->tun.wfResidentMax) : fits;
+      if (n > (ctx->tun.wfResidentMax > 0 ? cap : fitsWhole))
+        wfResident = srtHybridRecords(nodes, world, d->numTriangles, d->numSpheres, cap, nodesWf, worldWf, primSecond);
     }
   }
   std::vector<uint8_t> primClass((size_t)2 * std::max(d->numTriangles, d->numSpheres) + 2, 2);
@@ -1667,6 +1537,33 @@ int srtGetWfProfile(SrtContext* ctx, uint64_t* out46) {
   HIP_OK(ctx, hipDeviceSynchronize());
   HIP_OK(ctx, hipMemcpy(out46, ctx->dStats + 32, 46 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;
+}
+
+// Host-only test hooks for srt_thread.h (no device needed): nodes8 = numNodes x 8 floats, the flattened records.
+int srtTestThreadLinks16(const float* nodes8, int32_t numNodes, const int32_t* world, int32_t numWorld, int32_t numTriangles, int32_t numSpheres,
+                         int32_t* outLinks) {
+  if (!nodes8 || !world || !outLinks || numNodes < 0 || numWorld < 0) return -1;
+  std::vector<float4> nodes(2 * (size_t)numNodes);
+  if (numNodes) memcpy(nodes.data(), nodes8, nodes.size() * sizeof(float4));
+  std::vector<int32_t> links;
+  srtThreadLinks16(nodes, std::vector<int32_t>(world, world + numWorld), numTriangles, numSpheres, links);
+  if (links.empty()) return 0;
+  memcpy(outLinks, links.data(), links.size() * sizeof(int32_t));
+  return 1;
+}
+
+int srtTestHybridRecords(const float* nodes8, int32_t numNodes, const int32_t* world, int32_t numWorld, int32_t numTriangles, int32_t numSpheres,
+                         int32_t cap, float* outNodes8, int32_t* outWorld, int32_t* outSecond) {
+  if (!nodes8 || !world || !outNodes8 || !outWorld || !outSecond || numNodes < 0 || numWorld < 0 || cap < 0) return -1;
+  std::vector<float4> nodes(2 * (size_t)numNodes), wf;
+  if (numNodes) memcpy(nodes.data(), nodes8, nodes.size() * sizeof(float4));
+  std::vector<int32_t> w, second;
+  const int32_t resident = srtHybridRecords(nodes, std::vector<int32_t>(world, world + numWorld), numTriangles, numSpheres, (size_t)cap, wf, w, second);
+  if (resident <= 0) return 0;
+  memcpy(outNodes8, wf.data(), wf.size() * sizeof(float4));
+  memcpy(outWorld, w.data(), w.size() * sizeof(int32_t));
+  memcpy(outSecond, second.data(), second.size() * sizeof(int32_t));
+  return resident;
 }
 
 int srtGetShadeProfile(SrtContext* ctx, uint64_t* out10) {

@@ -35,7 +35,8 @@ EXPORTS = ["srtCreate", "srtDestroy", "srtLastError", "srtMakeCamera", "srtHostR
            "srtCommGetUniqueId", "srtCommInit", "srtGatherTiles", "srtRenderImageRanks", "srtCommDestroy",
            "srtLastKernelMs", "srtGetStats", "srtDeviceInfo"]
 # include/srt_hip_test.h: test hooks and diagnostics, not part of the drop-in boundary
-TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtGetWfProfile", "srtGetLaunchInfo", "srtRenderAov"]
+TEST_EXPORTS = ["srtScatterTest", "srtSetTunable", "srtGetTunable", "srtGetShadeProfile", "srtGetWfProfile", "srtGetLaunchInfo", "srtRenderAov",
+                "srtTestThreadLinks16", "srtTestHybridRecords"]
 
 _vp = C.c_void_p
 lib.srtCreate.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -75,6 +76,9 @@ lib.srtGetTunable.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int32)]
 lib.srtGetShadeProfile.argtypes = [_vp, _vp]
 lib.srtGetWfProfile.argtypes = [_vp, _vp]
 lib.srtGetLaunchInfo.argtypes = [_vp, _vp]
+lib.srtTestThreadLinks16.argtypes = [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]
+lib.srtTestHybridRecords.argtypes = [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]
+lib.srtTestThreadLinks16.restype = lib.srtTestHybridRecords.restype = C.c_int32
 lib.srtRenderAov.argtypes = [_vp, C.POINTER(abi.SrtRenderParams), C.c_int32, _vp]
 lib.srtLastKernelMs.argtypes = [_vp, C.POINTER(C.c_float)]
 lib.srtGetStats.argtypes = [_vp, C.POINTER(abi.SrtStats)]

@@ -352,7 +352,9 @@ const TunableName kTunables[] = {
     // many nodes (traversal-heavy frames gain, shading-heavy ones with tiny trees lose: profiles/r03/wavefront.txt); 0 = never
     {"wavefront", "SRT_WAVEFRONT", &Tunables::wavefront, 256},
     {"wf_pool", "SRT_WF_POOL", &Tunables::wfPool, 2048},       // path contexts per workgroup (1024 lanes traverse)
-    {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 32},
+    // lanes without a walk before a wave swaps finished walks for READY contexts; 0 = 32, and 16 in the hybrid form, whose
+    // lanes are worth more refilled than waiting (profiles/r03/hybrid.txt)
+    {"wf_swap_min", "SRT_WF_SWAP_MIN", &Tunables::wfSwapMin, 0},
     {"wf_swap_big", "SRT_WF_SWAP_BIG", &Tunables::wfSwapBig, 32},
     {"wf_profile", "SRT_WF_PROFILE", &Tunables::wfProfile, 0},  // 1: the profiling variant (tools/wf_profile.py, srtGetWfProfile)
     // closest-hit traversal: 128-byte records with four boxes (1, read at srtUploadScene) instead of the 64-byte two-box
@@ -1311,7 +1313,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfRingCap = wfRingCap;
     a.wfRingShift = wfRingShift;
     a.wfRingMul3 = wfRingMul3;
-    a.wfSwapMin = std::max(1, std::min(64, ctx->tun.wfSwapMin));
+    a.wfSwapMin = ctx->tun.wfSwapMin > 0 ? std::min(64, ctx->tun.wfSwapMin) : (hybrid ? 16 : 32);
     a.wfFarRounds = ctx->tun.wfFarRounds > 0 ? std::min(64, ctx->tun.wfFarRounds) : (5 * (int64_t)ctx->scene.wfResident >= ctx->scene.numNodes ? 2 : 1);
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));

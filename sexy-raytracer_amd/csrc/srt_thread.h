@@ -9,7 +9,7 @@
 // else; a caller-built tree may -- then the function returns nothing and the kernels walk with a stack):
 //   srtThreadLinks16   one word per node for the LDS-resident-tree kernels (DevScene::nodeThread)
 //   srtHybridRecords   the path-pool kernel's hybrid records (DevScene::nodesWf): 32-bit references, nodes renumbered
-// Pure host code (no HIP calls): tests/test_host_logic.py drives both through the test hooks of include/srt_hip_test.h and
+// Pure host code (no HIP calls): tests/test_thread_links.py drives both through the test hooks of include/srt_hip_test.h and
 // compares the stackless walks with the recursion.
 #pragma once
 #include <cstdint>
@@ -85,7 +85,8 @@ inline int32_t srtHybridRecords(const std::vector<float4>& nodes, const std::vec
   primSecond.clear();
   const size_t n = nodes.size() / 2;
   const int32_t kDoneW = -(1 << 29);
-  if (n == 0 || cap == 0 || n >= ((size_t)1 << 28) || numTriangles >= (1 << 27) || numSpheres >= (1 << 27) || !uniformChildren(nodes)) return 0;
+  // (a record's byte offset, index * 32, is a 32-bit buffer offset in the kernel: 2^26 nodes at most)
+  if (n == 0 || cap == 0 || n >= ((size_t)1 << 26) || numTriangles >= (1 << 27) || numSpheres >= (1 << 27) || !uniformChildren(nodes)) return 0;
   // successor of every node (original indices, -1 = done), pre-order of the world's trees
   std::vector<int32_t> succ(n, -2), preorder;
   preorder.reserve(n);

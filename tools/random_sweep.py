@@ -1,4 +1,6 @@
-"""One-off: many more randomised scenes than the suite holds, renders through both node paths against the oracle."""
+"""One-off: many more randomised scenes than the suite holds, rendered through the four forms of the FAITHFUL kernel (path pool,
+its hybrid form with a random cap on the LDS-resident nodes, step scheduler over the LDS tree, 256-thread kernel) against the oracle
+and against each other.  usage: python tools/random_sweep.py [scenes]"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,14 +15,23 @@ for seed in range(2000, 2000 + int(sys.argv[1]) if len(sys.argv) > 1 else 2060):
     osc = O.OracleScene(sb)
     p = abi.default_render_params(64, 36, 4, 6, seed=seed, count_stats=0)
     want, _, _ = osc.render(ocam, p, O.RNG_COUNTER, threads=8, want_stats=False)
-    for tree in (1, 0):
-        ctx.set_tunable("lds_tree", tree)
+    images = {}
+    for path, tun in (("wavefront", {"lds_tree": 1, "wavefront": 1}), ("hybrid", {"lds_tree": 1, "wavefront": 1, "wf_resident_max": 4 + seed % 29}),
+                      ("lds_tree", {"lds_tree": 1, "wavefront": 0}), ("l1_nodes", {"lds_tree": 0, "wavefront": 0})):
+        saved = {k: ctx.get_tunable(k) for k in tun}
+        for k, v in tun.items():
+            ctx.set_tunable(k, v)
         ctx.upload_scene(sb); ctx.set_camera(cam)
         acc, _ = ctx.render_image(p)
+        mode = ctx.launch_info()["lds_tree_mode"]
+        for k, v in saved.items():
+            ctx.set_tunable(k, v)
+        images[path] = acc
         nan_ok = np.array_equal(np.isnan(acc), np.isnan(want))
         bit = (acc.view(np.uint32) == want.view(np.uint32)).all(axis=-1).mean()
         ok = (np.isnan(want) | (np.abs(acc - want) <= 0.05 * np.maximum(np.abs(want), 1e-3) + 0.05)).mean()
-        flag = "" if (nan_ok and bit >= 0.98 and ok >= 0.999) else "  <-- CHECK"
+        same = np.array_equal(acc.view(np.uint32), images["wavefront"].view(np.uint32))  # the kernel forms agree bit for bit
+        flag = "" if (nan_ok and bit >= 0.98 and ok >= 0.999 and same) else "  <-- CHECK"
         bad += bool(flag)
-        print("seed %d tree %d: bit-exact %.4f within-tol %.4f nan %s lds %s%s" % (seed, tree, bit, ok, nan_ok, ctx.launch_info()["lds_tree"], flag), flush=True)
+        print("seed %d %-9s: bit-exact vs oracle %.4f within-tol %.4f nan %s forms-agree %s launch mode %d%s" % (seed, path, bit, ok, nan_ok, same, mode, flag), flush=True)
 print("flagged:", bad)

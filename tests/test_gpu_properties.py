@@ -305,6 +305,8 @@ def test_soup_scene_trace_and_render(ctx, oracle, abi, srt, camera):
         assert np.array_equal(got[f], want[f])
     p = abi.default_render_params(160, 90, 4, 4, seed=6)
     acc, _ = ctx.render_image(p)
+    # 40 k nodes: beyond LDS and beyond 16-bit references -- the path-pool kernel's hybrid form with its 32-bit links
+    assert ctx.launch_info()["lds_tree_mode"] == 4, ctx.launch_info()
     wacc, _, _ = osc.render(camera, p, oracle.RNG_COUNTER, threads=8, want_stats=False)
     bit = (acc.view(np.uint32) == wacc.view(np.uint32)).all(axis=-1)
     assert bit.mean() >= 0.995

@@ -574,7 +574,9 @@ def main():
         total_samples = W * H * spp * args.steps
         value = total_samples / elapsed / 1e6
         mode = launch.get("lds_tree_mode")
-        kernel_name = ("srt_render_wf_kernel<false,false,true>" if mode == 4 else "srt_render_wf_kernel<true,false,false>" if mode == 3 else
+        # (the bench scenes have one root; the hybrid form's single-root instance serves trees of up to 2^20 nodes: srt_launch_render_wf)
+        kernel_name = ("srt_render_wf_kernel<%s,false,true>" % ("true" if n_nodes <= (1 << 20) else "false") if mode == 4 else
+                       "srt_render_wf_kernel<true,false,false>" if mode == 3 else
                        "srt_render_kernel<%s,false,true,%s,%s>" % ("true" if traversal == "closest" else "false",
                                                                    "true" if launch["lds_tree"] else "false",
                                                                    "true" if launch.get("lds_tree_mode") == 2 else "false"))

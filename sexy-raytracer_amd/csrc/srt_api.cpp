@@ -370,8 +370,9 @@ const TunableName kTunables[] = {
     // this path (the parity tests set it to a few dozen).  Both are read at srtUploadScene.
     {"wf_hybrid", "SRT_WF_HYBRID", &Tunables::wfHybrid, 1},
     {"wf_resident_max", "SRT_WF_RESIDENT_MAX", &Tunables::wfResidentMax, 0},
-    // hybrid form: node visits per round (srt_wavefront.hip); 0 = 2 when at least a fifth of the nodes is resident, else 1
-    // (profiles/r03/hybrid.txt)
+    // hybrid form: node visits per round, 1..4 (srt_wavefront.hip): the first of two overlaps the other lanes' loads.
+    // 0 = 2 for trees of up to 2^20 nodes (cache-resident: +10 % and more), 1 beyond (HBM-bound soups of 4 M and 10 M
+    // triangles lose 5-10 % with 2) -- profiles/r03/hybrid.txt
     {"wf_far_rounds", "SRT_WF_FAR_ROUNDS", &Tunables::wfFarRounds, 0},
 };
 
@@ -1314,7 +1315,7 @@ static int srtRenderTilesImpl(SrtContext* ctx, const SrtRenderParams* p, void* d
     a.wfRingShift = wfRingShift;
     a.wfRingMul3 = wfRingMul3;
     a.wfSwapMin = ctx->tun.wfSwapMin > 0 ? std::min(64, ctx->tun.wfSwapMin) : (hybrid ? 16 : 32);
-    a.wfFarRounds = ctx->tun.wfFarRounds > 0 ? std::min(64, ctx->tun.wfFarRounds) : (5 * (int64_t)ctx->scene.wfResident >= ctx->scene.numNodes ? 2 : 1);
+    a.wfFarRounds = ctx->tun.wfFarRounds > 0 ? std::min(4, ctx->tun.wfFarRounds) : (ctx->scene.numNodes <= (1 << 20) ? 2 : 1);
     a.wfSwapBig = std::max(a.wfSwapMin, std::min(64, ctx->tun.wfSwapBig));
     HIP_OK(ctx, hipHostGetDevicePointer((void**)&a.wfError, ctx->dWfError, 0));
   } else if (ldsTreeMode == 1 || attGlobal256) {

@@ -392,15 +392,15 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           // or until none of them is at one) and then fetch one more record from LDS, so that the last visit of the round
           // serves both groups in one execution
           const bool far = cur >= resident;
-          float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
+          float4 g0, g1;  // (read only by the lanes that load them below)
           if (far) {
             g0 = bufLoad4(rsNodes, cur << 5);
             g1 = bufLoad4(rsNodes, (cur << 5) + 16);
           }
-          for (int u = 1; u < a.wfFarRounds; ++u) {
-            if (__ballot(!far && (uint32_t)cur < (uint32_t)resident) == 0) break;
-            nodeVisit(!far);
-          }
+          // no loop here: a loop header makes the compiler wait for the loads above before the LDS visits begin
+          if (a.wfFarRounds > 1) nodeVisit(!far);
+          if (a.wfFarRounds > 2) nodeVisit(!far);
+          if (a.wfFarRounds > 3) nodeVisit(!far);
           const bool near = !far && (uint32_t)cur < (uint32_t)resident;
           if (near) {
             const char* rec = ldsTree + (cur << 5);
@@ -821,7 +821,11 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
 extern "C" {
 int srt_launch_render_wf(const RenderArgs* a, int profile, int grid, size_t ldsBytes, hipStream_t stream) {
   typedef void (*Kernel)(const RenderArgs);
-  const Kernel k = a->scene.nodesWf ? (profile ? srt_render_wf_kernel<false, true, true> : srt_render_wf_kernel<false, false, true>)
+  // (hybrid form: the single-root instance is worth +12 to +15 % on cache-resident trees and costs 5 % on the HBM-bound
+  // soups of 4 M triangles and more, where the shorter visit only crowds the memory system: profiles/r03/hybrid.txt)
+  const Kernel k = a->scene.nodesWf ? (profile ? srt_render_wf_kernel<false, true, true>
+                                       : a->scene.numWorld == 1 && a->scene.numNodes <= (1 << 20) ? srt_render_wf_kernel<true, false, true>
+                                                                                                   : srt_render_wf_kernel<false, false, true>)
                    : profile       ? srt_render_wf_kernel<false, true, false>
                                    : (a->scene.numWorld == 1 ? srt_render_wf_kernel<true, false, false> : srt_render_wf_kernel<false, false, false>);
   if (ldsBytes > 64 * 1024) {

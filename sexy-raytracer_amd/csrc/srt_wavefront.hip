@@ -184,11 +184,14 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     }
     if (ring >= 0) {
       uint16_t* const s = ringSlots + ring * RCAP + ringPos((uint32_t)(myBase + __popcll(mine & laneBelow)));
-      int spins = 0;
-      while (__hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG) != 0) {
-        if (++spins > WF_SPIN_LIMIT) {
-          raiseAbort();
-          break;
+      // (first look outside the loop: a loop header makes the compiler wait for every load the caller has in flight)
+      if (__hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG) != 0) {
+        int spins = 0;
+        while (__hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG) != 0) {
+          if (++spins > WF_SPIN_LIMIT) {
+            raiseAbort();
+            break;
+          }
         }
       }
       __hip_atomic_store(s, (uint16_t)(id + 1), __ATOMIC_RELAXED, WF_WG);
@@ -202,7 +205,23 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       const unsigned long long th = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&ctl[WF_CTL_TAIL(r)]), __ATOMIC_RELAXED, WF_WG);
       int t = (int)th;
       h = (int)(th >> 32);
-      for (;;) {
+      // first attempt outside the loop (as in enqueue: no loop header on the common path)
+      bool again = false;
+      {
+        const int avail = (int)((uint32_t)t - (uint32_t)h);
+        k = avail < want ? avail : want;
+        if (k < atLeast || k <= 0) {
+          k = 0;
+        } else {
+          int expected = h;
+          if (!__hip_atomic_compare_exchange_strong(&ctl[WF_CTL_HEAD(r)], &expected, h + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, WF_WG)) {
+            h = expected;  // another wave claimed meanwhile: the tail can only have grown
+            again = true;
+          }
+        }
+      }
+      while (again) {
+        t = __hip_atomic_load(&ctl[WF_CTL_TAIL(r)], __ATOMIC_RELAXED, WF_WG);
         const int avail = (int)((uint32_t)t - (uint32_t)h);
         k = avail < want ? avail : want;
         if (k < atLeast || k <= 0) {
@@ -211,8 +230,7 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
         }
         int expected = h;
         if (__hip_atomic_compare_exchange_strong(&ctl[WF_CTL_HEAD(r)], &expected, h + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, WF_WG)) break;
-        h = expected;  // another wave claimed meanwhile: the tail can only have grown
-        t = __hip_atomic_load(&ctl[WF_CTL_TAIL(r)], __ATOMIC_RELAXED, WF_WG);
+        h = expected;
       }
     }
     h = __builtin_amdgcn_readfirstlane(h);
@@ -221,11 +239,14 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     const int rank = __popcll(takers & laneBelow);
     if (((takers >> lane) & 1ull) && rank < k) {
       uint16_t* const s = ringSlots + r * RCAP + ringPos((uint32_t)(h + rank));
-      int v, spins = 0;
-      while ((v = __hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG)) == 0) {
-        if (++spins > WF_SPIN_LIMIT) {
-          raiseAbort();
-          break;
+      int v = __hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG);
+      if (v == 0) {
+        int spins = 0;
+        while ((v = __hip_atomic_load(s, __ATOMIC_RELAXED, WF_WG)) == 0) {
+          if (++spins > WF_SPIN_LIMIT) {
+            raiseAbort();
+            break;
+          }
         }
       }
       __hip_atomic_store(s, (uint16_t)0, __ATOMIC_RELAXED, WF_WG);

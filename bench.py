@@ -72,6 +72,7 @@ WORKLOADS = {
     # a tree that is cache-resident but does not fit a CU's LDS (66 k nodes, 2 MB): the 256-thread kernel's regime, bound by
     # the vector-memory address unit (what treelets are for)
     "soup_50k_720p_64spp": ("soup:50000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),
+    "soup_200k_720p_64spp": ("soup:200000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),
     # (five copies of the mesh: 16.7 k nodes; a 16 k-triangle soup: the 256-thread kernel on trees just beyond a CU's LDS)
     "army_720p_1024spp": ("army", 1280, 720, 1024, 4, "reference", "faithful", "valu-issue"),
     "soup_16k_720p_64spp": ("soup:16000", 1280, 720, 64, 4, "reference", "faithful", "valu-issue"),

@@ -247,7 +247,10 @@ void srtHostRandomReset(void);
 
 /* replaces hittableVector::build + the SSBO upload (hittablevector.h:27-31,
  * gl.h:240-262): builds every SRT_WORLD_BVH with bvh.h:55-95 semantics,
- * precomputes per-triangle constants, copies everything to HBM. */
+ * precomputes per-triangle constants, copies everything to HBM.
+ * Device memory: 32 B per node, 112 B per triangle, 48 B per sphere, the texels; trees too large for a compute
+ * unit's LDS (more than about 4 500 nodes) get a second, threaded copy of the node array for the render kernel
+ * that keeps their top in LDS: +32 B per node, +8 B per primitive. */
 int srtUploadScene(SrtContext* ctx, const SrtSceneDesc* scene);
 int srtSetCamera(SrtContext* ctx, const SrtCamera* cam);
 

@@ -100,6 +100,38 @@ def test_sample_sum_linearity(ctx, abi, srt, camera):
     assert abs(other[..., :3].mean() - seq[..., :3].mean()) < 0.01 * seq[..., :3].mean()
 
 
+def test_hybrid_form_on_odd_shapes(ctx, dev, abi, srt, camera):
+    """The path-pool kernel's hybrid form (what a tree beyond LDS gets by default) against the 256-thread kernel where its
+    bookkeeping is least comfortable: more bounces than a context line holds attenuations for, frames smaller than a
+    workgroup's pool of contexts, a rank's share of the tiles, a sample range that starts late (progressive pass), one
+    chunk and many.  Same accumulators, bit for bit."""
+    import torch
+    sb = srt.scenes.scene_soup(30000, seed=9, extent=5.0, size=0.12)
+    cases = [  # width, height, spp, bounces, chunks, tile_first, tile_stride, sample_first
+        (33, 17, 3, 12, 1, 0, 1, 0), (200, 120, 24, 9, 0, 0, 1, 0), (320, 180, 16, 6, 5, 2, 3, 0), (160, 90, 8, 4, 0, 0, 1, 40)]
+    out = {}
+    for hybrid in (1, 0):
+        ctx.set_tunable("wf_hybrid", hybrid)
+        try:
+            ctx.upload_scene(sb)
+        finally:
+            ctx.set_tunable("wf_hybrid", 1)
+        ctx.set_camera(camera)
+        for case in cases:
+            w, h, spp, mb, chunks, first, stride, s0 = case
+            p = abi.default_render_params(w, h, spp, mb, seed=21, spp_chunks=chunks, tile_first=first, tile_stride=stride, sample_first=s0)
+            local = torch.zeros((dev.num_local_tiles(w, h, stride), 64, 4), dtype=torch.float32, device="cuda")
+            ctx.render_tiles(p, local.data_ptr(), None)
+            torch.cuda.synchronize()
+            ctx.last_kernel_ms()  # raises if a path-pool workgroup gave up
+            assert ctx.launch_info()["lds_tree_mode"] == (4 if hybrid else 0), (case, ctx.launch_info())
+            out[(hybrid, case)] = local.cpu().numpy()
+    for case in cases:
+        a, b = out[(1, case)], out[(0, case)]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), case
+        assert (a[..., 3] > 0).any()
+
+
 def test_image_independent_of_work_distribution(ctx, abi, srt, camera):
     """The tile order, the number of work queues and the unit size decide only WHO renders WHAT WHEN
     (csrc/srt_kernels.hip "work queues"): the image must not change, also when every queue has to be

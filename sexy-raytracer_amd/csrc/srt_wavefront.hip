@@ -376,10 +376,10 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       }
       return nNodes;
   };
-  auto nodeBurst = [&](int nNodes) {
+  auto nodeBurst = [&](int nNodes) -> int {  // returns the lanes at nodes afterwards
       // ------------------------------------------------ bvhNode::hit, bvh.h:97-105, over the threaded tree in LDS
       const int keep = (nNodes * a.keepEighths) >> 3;
-      int budget = a.nodeBurst;
+      int budget = a.nodeBurst, left;
       auto visit = [&](const float4 n0, const float4 n1) {  // aabb::hit (certified slab test, IEEE when undecided), then on
         bool undecided;
         bool hitBox = boxHitApprox<true>(n0, n1, rcpD, negOR, slabTol, a.tMin, closest, undecided);
@@ -441,12 +441,14 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
           for (int u = 0; u < SRT_NODE_UNROLL; ++u) nodeVisit(true);
         }
         budget -= HYBRID ? a.wfFarRounds : SRT_NODE_UNROLL;
-      } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
+        left = __popcll(__ballot(atNode()));
+      } while (budget > 0 && left >= keep);
       if (PROFILE) {
         const unsigned long long now = clock64();
         pCyc[0] += now - pT;
         pT = now;
       }
+      return left;
   };
   // ---- swap step: finished walks out, READY contexts in
   auto swapStep = [&]() {
@@ -742,16 +744,21 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[32 + 3 * WF_PROF_KINDS + 2 + k], pSaw[k]);
     }
   };
+  bool traverseFirst = false;  // the last decision was "go on traversing": one step before the rings are looked at again
   for (;;) {
     // ---- traverse for as long as the rings need no look: a tight loop of node bursts and primitive steps.  The rings are
     // looked at (below) when this wave has lanes to refill, nothing to traverse, or every fourth pass: with sixteen waves
-    // deciding, a full batch is still seen within a fraction of the time it took to fill.
-    int nN, nP, free;
+    // deciding, a full batch is still seen within a fraction of the time it took to fill.  EVERY traversal step runs in
+    // this loop (a decision that picks one comes back here with traverseFirst set): a second place to run them made the
+    // compiler copy the lanes' whole state, forty registers, on its way back to the loop header.
+    int nN, nP, free, nNknown = -1;  // (a step that ends with a count of the lanes at nodes hands it to the next pass)
     for (;;) {
-      nN = __popcll(__ballot(atNode()));
+      nN = nNknown >= 0 ? nNknown : __popcll(__ballot(atNode()));
       nP = __popcll(__ballot(atPrim()));
       free = 64 - nN - nP;  // lanes whose walk is over or that hold no context (cur == DONE either way)
-      if (free >= a.wfSwapMin || nN + nP == 0 || (++tick & 3u) == 0) break;
+      if (nN + nP == 0) break;
+      if (!traverseFirst && (free >= a.wfSwapMin || (++tick & 3u) == 0)) break;
+      traverseFirst = false;
       if (PROFILE) {
         const unsigned long long now = clock64();
         pSched += now - pT;
@@ -759,9 +766,9 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       }
       if (nP >= a.primMin || nN == 0) {
         const int nNodes = primStep();
-        if (nNodes >= a.fuseMin) nodeBurst(nNodes);
+        nNknown = nNodes >= a.fuseMin ? nodeBurst(nNodes) : nNodes;
       } else {
-        nodeBurst(nN);
+        nNknown = nodeBurst(nN);
       }
     }
     // ---- scheduling decision with the rings in view
@@ -825,11 +832,8 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
       pT = now;
     }
 
-    if (pick == W_PRIM) {
-      const int nNodes = primStep();
-      if (nNodes >= a.fuseMin) nodeBurst(nNodes);
-    } else if (pick == W_NODE) {
-      nodeBurst(nN);
+    if (pick == W_PRIM || pick == W_NODE) {
+      traverseFirst = true;  // (the loop above picks the step by the same rule)
     } else if (pick == W_SWAP) {
       swapStep();
     } else if (pick == W_SERVE) {

@@ -247,12 +247,22 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
     pend = 1;  // a miss unless a hit-shading step says otherwise
   };
 
+  // Two loop levels: the traversal steps run in the inner one, where the lanes' ray (origin, direction, reciprocals, ...) is
+  // loop-invariant; the shading steps, which replace it, in the outer one.  With all four step kinds in ONE loop the
+  // compiler copied that state -- some forty registers, twice -- on every trip back to the loop header.
   for (;;) {
+    int pick, pk, nS = 0, nH = 0;
+    unsigned long long pT0 = 0;
+    for (;;) {
     const unsigned long long mN = __ballot(atNode()), mP = __ballot(atPrim()), mS = __ballot(atRestart()),
                              mH = __ballot(atHit());
-    const int nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nH = __popcll(mH);
-    if ((nN | nP | nS | nH) == 0) break;
-    int pick;
+    const int nN = __popcll(mN), nP = __popcll(mP);
+    nS = __popcll(mS);
+    nH = __popcll(mH);
+    if ((nN | nP | nS | nH) == 0) {
+      pick = -1;
+      break;
+    }
     if (nH >= a.hitMin || (nN | nP | nS) == 0)
       pick = M_HIT;
     else if (nS >= a.shadeMin || (nN | nP) == 0)
@@ -262,13 +272,14 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
     else
       pick = M_NODE;
     pick = __builtin_amdgcn_readfirstlane(pick);
-    unsigned long long pT0 = COUNT ? clock64() : 0;
-    int pk = pick == M_HIT ? 2 : pick;  // profile slot: hit shading and restarts share the "shade" row
+    pT0 = COUNT ? clock64() : 0;
+    pk = pick == M_HIT ? 2 : pick;  // profile slot: hit shading and restarts share the "shade" row
     if (COUNT && pick != M_NODE) {
       pSteps[pk]++;
       pLanes[pk] += pick == M_PRIM ? nP : (pick == M_HIT ? nH : nS);
     }
 
+    if (pick == M_HIT || pick == M_SHADE) break;  // -> the outer level
     int nNodes = nN;
     if (pick == M_PRIM) {
       // ------------------------------------------------ sphere::hit / triangle::hit
@@ -495,7 +506,11 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
         for (int u = 0; u < UNROLL; ++u) nodeVisit();
         budget -= UNROLL;
       } while (budget > 0 && __popcll(__ballot(atNode())) >= keep);
-    } else if (pick == M_HIT) {
+    }
+    if (COUNT) pCyc[pk] += clock64() - pT0;
+    }  // traversal steps
+    if (pick < 0) break;
+    if (pick == M_HIT) {
       // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
       const unsigned long long h0 = COUNT ? clock64() : 0;
       unsigned long long hStamp[2] = {h0, h0}, h1 = h0;
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
         pSub[2] += t3 - t2;
         pSub[3] += h4 - t3;
       }
-    } else if (pick == M_SHADE) {
+    } else {
       // ------------------------------------------------ path restart: miss / path end (main.cpp:39-40,49-51),
       // pixel sum (main.cpp:217), next work item, next camera ray (main.cpp:204-216)
       const unsigned long long r0 = COUNT ? clock64() : 0;

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
     if (COUNT) pCyc[pk] += clock64() - pT0;
     }  // traversal steps
     if (pick < 0) break;
+    bool go = false;  // this lane has a new ray to send into the world
     if (pick == M_HIT) {
       // ------------------------------------------------ rayColor's hit branch (main.cpp:42-51): one path vertex
       const unsigned long long h0 = COUNT ? clock64() : 0;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
           pend = 2;
           hitRef = DONE;  // shaded: the lane now waits for a restart step
         } else {
-          startTraversal();
+          go = true;  // -> startTraversal() below, one copy of it for both shading steps
         }
       }
       if (COUNT) {
@@ -703,12 +704,13 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
           cameraRay(a.cam, u, v, rng, ray);
           depth = 0;
           if (COUNT) cSamples++;
-          startTraversal();
+          go = true;
         }
         // else: exit, or an empty item (pixel outside the image): stays in M_SHADE and pulls again
       }
       if (COUNT) pSub[4] += clock64() - r0;
     }
+    if (go) startTraversal();
     if (COUNT) pCyc[pk] += clock64() - pT0;
   }
 

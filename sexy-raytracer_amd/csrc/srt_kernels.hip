@@ -701,7 +701,8 @@ __global__ __launch_bounds__(LDSTREE ? SRT_BLOCK_TREE : SRT_BLOCK, LDSTREE ? SRT
           rng.key(seedMixed, pixel, (uint32_t)s);
           float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
           float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
-          cameraRay(a.cam, u, v, rng, ray);
+          const DevCamera cam = cameraFromKernarg();
+          cameraRay(cam, u, v, rng, ray);
           depth = 0;
           if (COUNT) cSamples++;
           go = true;

@@ -745,6 +745,28 @@ __device__ __forceinline__ bool shade(const DevScene& sc, Rsrc rsTexels, const R
   }
 }
 
+// The camera as the kernel argument segment holds it, read where it is used (scalar loads of 27 words) instead of at the
+// kernel's entry: the render kernels are one big loop, values loaded up front stay live through all of it, and the scalar
+// registers they take are spilled into vector-register lanes and read back lane by lane -- on the vector ALU -- at every
+// restart step.  `RenderArgs` must be the kernel's only argument (offset 0 of the segment).
+__device__ __forceinline__ DevCamera cameraFromKernarg() {
+  DevCamera c;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const unsigned char ConstByte;
+  typedef __attribute__((address_space(4))) const float ConstFloat;
+  ConstByte* p = (ConstByte*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));  // not hoisted out of the loop it is called in
+  ConstFloat* f = (ConstFloat*)(p + offsetof(RenderArgs, cam));
+  static_assert(sizeof(DevCamera) % sizeof(float) == 0, "DevCamera is all floats");
+  float* out = reinterpret_cast<float*>(&c);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(DevCamera) / sizeof(float)); ++k) out[k] = f[k];
+#else
+  c = DevCamera();
+#endif
+  return c;
+}
+
 // camera::getRay, camera.h:40-46
 __device__ __forceinline__ void cameraRay(const DevCamera& c, float s, float t, Pcg& rng, Ray& r) {
   float dx, dy;

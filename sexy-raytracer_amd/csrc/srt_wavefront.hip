@@ -305,7 +305,8 @@ __global__ __launch_bounds__(WF_BLOCK, 4) void srt_render_wf_kernel(const Render
     const float u = ((float)px + rng.uniform()) / (float)(a.imageWidth - 1);                      // main.cpp:210
     const float v = ((float)(a.imageHeight - py) + rng.uniform()) / (float)(a.imageHeight - 1);  // main.cpp:211
     Ray r;
-    cameraRay(a.cam, u, v, rng, r);
+    const DevCamera cam = cameraFromKernarg();
+    cameraRay(cam, u, v, rng, r);
     bufStore4(rsPool, at, make_float4(r.o.x, r.o.y, r.o.z, r.time));
     bufStore4(rsPool, at + 16, make_float4(r.d.x, r.d.y, r.d.z, 0.0f));
     u32x4 Cn;
